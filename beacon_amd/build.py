@@ -1,0 +1,76 @@
+"""In-tree build of libbeacon_hip.so (hand-written HIP for gfx950) with hipcc.
+
+The shared object is git-ignored but travels to the GPU box with the snapshot; it is
+rebuilt whenever a source under csrc/ or include/ is newer than it."""
+import glob
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(os.path.dirname(PKG), "include")
+LIB = os.path.join(PKG, "libbeacon_hip.so")
+OBJ = os.path.join(PKG, "csrc", "_obj")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _deps():
+    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 and link libbeacon_hip.so.  Returns its path."""
+    if not force and not stale():
+        return LIB
+    cc = hipcc()
+    if cc is None:
+        raise RuntimeError("hipcc not found: cannot build libbeacon_hip.so")
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(f) for f in _deps() if f.endswith(".h"))
+
+    def one(src):
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > hdr_t):
+            return obj
+        cmd = [cc] + FLAGS + ["-I", INC, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, sources()))
+    cmd = [cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

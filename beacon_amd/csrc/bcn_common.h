@@ -1,0 +1,79 @@
+// bcn_common.h -- shared host/device helpers for libbeacon_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/beacon_hip.h"
+
+#define BCN_WAVE 64
+
+void bcn_set_error(const char* fmt, ...);
+
+#define BCN_HIP(call)                                                                      \
+  do {                                                                                     \
+    hipError_t e__ = (call);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      bcn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return BCN_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+// ---- wave / workgroup reductions (wave = 64 lanes) ---------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, BCN_WAVE);
+  return v;
+}
+
+// Sum over the workgroup; every thread gets the same value (same summation order, so a
+// branch on it is uniform).  `red` is LDS scratch of >= NT/64 elements; callers alternate
+// between two scratch rows so that ONE barrier per call is enough.
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+  constexpr int NW = NT / BCN_WAVE;
+  v = wave_sum(v);
+  if ((threadIdx.x & (BCN_WAVE - 1)) == 0) red[threadIdx.x / BCN_WAVE] = v;
+  __syncthreads();
+  T s = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) s += red[w];
+  return s;
+}
+
+template <typename T>
+__device__ __forceinline__ T bcn_abs(T x) { return x < T(0) ? -x : x; }
+
+// ---- handle ------------------------------------------------------------------------------
+struct bcn_env_s {
+  int kind = -1;
+  int batch = 0;
+  int dtype = BCN_F32;
+  int device = 0;
+  int n_obs = 0;
+  int n_act = 0;
+  int variant = 0;
+  size_t esz = 4;
+  virtual ~bcn_env_s() {}
+  virtual size_t state_elems() const = 0;
+  virtual int get_state(void* buf, int is_device, hipStream_t s) = 0;
+  virtual int set_state(const void* buf, int is_device, hipStream_t s) = 0;
+  virtual int set_variant(int v) { variant = 0; (void)v; return 0; }
+  virtual const char* kernel_name() const = 0;
+  int32_t* stp = nullptr;  // device int32[B]
+};
+
+// device allocation tracked per handle
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t n) {
+    bytes = n;
+    hipError_t e = hipMalloc(&p, n ? n : 4);
+    if (e != hipSuccess) { bcn_set_error("hipMalloc(%zu): %s", n, hipGetErrorString(e)); return BCN_ERR_HIP; }
+    return BCN_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; }
+};

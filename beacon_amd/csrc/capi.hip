@@ -1,0 +1,510 @@
+// capi.hip -- extern "C" surface of libbeacon_hip.so (include/beacon_hip.h): handle
+// management, argument-block construction (derived constants are computed here in double and
+// narrowed once), state copies.  All device work is enqueued on the caller's stream.
+#include <stdarg.h>
+
+#include <new>
+#include <vector>
+
+#include "env1d.h"
+#include "ns2d.h"
+
+static thread_local char g_err[512] = "";
+
+void bcn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+struct DeviceGuard {
+  int prev = 0;
+  explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); (void)hipSetDevice(dev); }
+  ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
+// ------------------------------------------------------------------------------------------
+// rayleigh / mixing
+// ------------------------------------------------------------------------------------------
+template <typename real>
+struct NS2DEnv : bcn_env_s {
+  NS2DArgs<real> a{};
+  DevBuf fields;    // u,v,p,S,us,vs   [6][B][ncell]
+  DevBuf work;      // g0,g1,g2        [3][B][ncell]  (only when the work arrays do not fit LDS)
+  DevBuf obs_hist, a_last, ia_last, stpbuf;
+  bool fast_ok = false;
+
+  int init() {
+    const size_t per = (size_t)batch * a.ncell * sizeof(real);
+    int rc;
+    if ((rc = fields.alloc(6 * per))) return rc;
+    BCN_HIP(hipMemset(fields.p, 0, 6 * per));
+    real* f = static_cast<real*>(fields.p);
+    const size_t n = (size_t)batch * a.ncell;
+    a.u = f; a.v = f + n; a.p = f + 2 * n; a.S = f + 3 * n; a.us = f + 4 * n; a.vs = f + 5 * n;
+    const bool in_lds = ns2d_generic_lds_bytes(a.ncell, sizeof(real)) > (2 * 16 + 64) * sizeof(real);
+    if (!in_lds) {
+      if ((rc = work.alloc(3 * per))) return rc;
+      real* w = static_cast<real*>(work.p);
+      a.g0 = w; a.g1 = w + n; a.g2 = w + 2 * n;
+    }
+    if ((rc = obs_hist.alloc((size_t)batch * a.n_obs * sizeof(real)))) return rc;
+    BCN_HIP(hipMemset(obs_hist.p, 0, obs_hist.bytes));
+    a.obs_hist = static_cast<real*>(obs_hist.p);
+    if ((rc = a_last.alloc((size_t)batch * (a.n_sgts > 0 ? a.n_sgts : 1) * sizeof(real)))) return rc;
+    BCN_HIP(hipMemset(a_last.p, 0, a_last.bytes));
+    a.a_last = static_cast<real*>(a_last.p);
+    if ((rc = ia_last.alloc((size_t)batch * sizeof(int32_t)))) return rc;
+    BCN_HIP(hipMemset(ia_last.p, 0, ia_last.bytes));
+    a.ia_last = static_cast<int32_t*>(ia_last.p);
+    if ((rc = stpbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
+    BCN_HIP(hipMemset(stpbuf.p, 0, stpbuf.bytes));
+    stp = a.stp = static_cast<int32_t*>(stpbuf.p);
+    fast_ok = ns2d_fast_supported<real>(a);
+    variant = fast_ok ? 1 : 0;
+    return BCN_OK;
+  }
+  ~NS2DEnv() override {
+    DeviceGuard g(device);
+    fields.release(); work.release(); obs_hist.release(); a_last.release(); ia_last.release();
+    stpbuf.release();
+  }
+  size_t state_elems() const override { return 4 * (size_t)a.ncell; }
+  // state buffer layout: [B][4][ncell]; device layout: [4][B][ncell]
+  int copy_state(void* buf, int is_device, hipStream_t s, bool out) {
+    const size_t row = (size_t)a.ncell * sizeof(real);
+    real* f = static_cast<real*>(fields.p);
+    for (int k = 0; k < 4; k++) {
+      char* ext = static_cast<char*>(buf) + (size_t)k * row;
+      real* dev = f + (size_t)k * batch * a.ncell;
+      hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+      if (out) BCN_HIP(hipMemcpy2DAsync(ext, 4 * row, dev, row, row, batch, kind, s));
+      else BCN_HIP(hipMemcpy2DAsync(dev, row, ext, 4 * row, row, batch, kind, s));
+    }
+    if (!is_device) BCN_HIP(hipStreamSynchronize(s));
+    return BCN_OK;
+  }
+  int get_state(void* buf, int is_device, hipStream_t s) override { return copy_state(buf, is_device, s, true); }
+  int set_state(const void* buf, int is_device, hipStream_t s) override {
+    return copy_state(const_cast<void*>(buf), is_device, s, false);
+  }
+  int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; return variant; }
+  const char* kernel_name() const override { return variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step"; }
+  int launch(hipStream_t s) {
+    if (variant == 1) return ns2d_launch_fast<real>(a, batch, s);
+    return ns2d_launch_generic<real>(a, batch, s);
+  }
+};
+
+template <typename real>
+void ns2d_common(NS2DArgs<real>& a, int nx, int ny, double dx, double dy, double dt, double tol) {
+  a.nx = nx; a.ny = ny; a.sx = nx + 2; a.ncell = (nx + 2) * (ny + 2);
+  a.dt = (real)dt; a.rdx = (real)(1.0 / dx); a.rdy = (real)(1.0 / dy);
+  a.rdx2 = (real)(1.0 / (dx * dx)); a.rdy2 = (real)(1.0 / (dy * dy));
+  const double den = dx * dx + dy * dy;
+  a.cx = (real)(0.5 * dy * dy / den);
+  a.cy = (real)(0.5 * dx * dx / den);
+  a.cb = (real)(0.5 * dx * dx * dy * dy / den / dt);
+  a.tol = (real)tol;
+}
+
+template <typename real>
+int make_rayleigh(const bcn_rayleigh_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  auto* e = new (std::nothrow) NS2DEnv<real>();
+  if (!e) { bcn_set_error("out of host memory"); return BCN_ERR_ARG; }
+  e->kind = BCN_RAYLEIGH; e->batch = batch; e->dtype = dtype; e->device = device; e->esz = sizeof(real);
+  NS2DArgs<real>& a = e->a;
+  ns2d_common(a, c->nx, c->ny, c->dx, c->dy, c->dt, c->tol);
+  a.kind = 0; a.ndt_act = c->ndt_act; a.n_act = c->n_act; a.itmax = c->itmax;
+  a.n_sgts = c->n_sgts; a.nx_sgts = c->nx_sgts;
+  a.nxo = c->nx_obs_pts; a.nyo = c->ny_obs_pts; a.nx_obs = c->nx_obs; a.ny_obs = c->ny_obs;
+  a.n_obs_steps = c->n_obs_steps; a.n_obs = 3 * c->n_obs_steps * c->nx_obs_pts * c->ny_obs_pts;
+  a.kmom = (real)sqrt(c->pr / c->ra);
+  a.ksc = (real)(1.0 / sqrt(c->pr * c->ra));
+  a.Tc = (real)c->Tc; a.Th = (real)c->Th; a.C = (real)c->C;
+  a.rwd_scale = (real)(1.0 / (0.5 * c->dy * c->nx));
+  e->n_obs = a.n_obs; e->n_act = c->n_sgts;
+  int rc = e->init();
+  if (rc) { delete e; return rc; }
+  *out = e;
+  return BCN_OK;
+}
+
+template <typename real>
+int make_mixing(const bcn_mixing_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  auto* e = new (std::nothrow) NS2DEnv<real>();
+  if (!e) { bcn_set_error("out of host memory"); return BCN_ERR_ARG; }
+  e->kind = BCN_MIXING; e->batch = batch; e->dtype = dtype; e->device = device; e->esz = sizeof(real);
+  NS2DArgs<real>& a = e->a;
+  ns2d_common(a, c->nx, c->ny, c->dx, c->dy, c->dt, c->tol);
+  a.kind = 1; a.ndt_act = c->ndt_act; a.n_act = c->n_act; a.itmax = c->itmax;
+  a.n_sgts = 0; a.nx_sgts = 1;
+  a.nxo = c->nx_obs_pts; a.nyo = c->ny_obs_pts; a.nx_obs = c->nx_obs; a.ny_obs = c->ny_obs;
+  a.n_obs_steps = c->n_obs_steps; a.n_obs = 3 * c->n_obs_steps * c->nx_obs_pts * c->ny_obs_pts;
+  a.i_min = c->i_min; a.i_max = c->i_max; a.j_min = c->j_min; a.j_max = c->j_max;
+  a.kmom = (real)(1.0 / c->re);
+  a.ksc = (real)(1.0 / c->pe);
+  a.u_max = (real)c->u_max; a.ref_c = (real)c->ref_c; a.C0 = (real)c->C0;
+  e->n_obs = a.n_obs; e->n_act = 1;
+  int rc = e->init();
+  if (rc) { delete e; return rc; }
+  *out = e;
+  return BCN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// 1D envs
+// ------------------------------------------------------------------------------------------
+template <typename real>
+struct Env1D : bcn_env_s {
+  Env1DArgs<real> a{};
+  int nfields = 4;
+  DevBuf fields, a_last, a_prev, stpbuf;
+  const char* kname = "";
+
+  int init(int n_actions) {
+    int rc;
+    const size_t per = (size_t)batch * a.n * sizeof(real);
+    if ((rc = fields.alloc(4 * per))) return rc;
+    BCN_HIP(hipMemset(fields.p, 0, 4 * per));
+    real* f = static_cast<real*>(fields.p);
+    const size_t n = (size_t)batch * a.n;
+    a.f0 = f; a.f1 = f + n; a.f2 = f + 2 * n; a.f3 = f + 3 * n;
+    if ((rc = a_last.alloc((size_t)batch * n_actions * sizeof(real)))) return rc;
+    if ((rc = a_prev.alloc((size_t)batch * n_actions * sizeof(real)))) return rc;
+    BCN_HIP(hipMemset(a_last.p, 0, a_last.bytes));
+    BCN_HIP(hipMemset(a_prev.p, 0, a_prev.bytes));
+    a.a_last = static_cast<real*>(a_last.p);
+    a.a_prev = static_cast<real*>(a_prev.p);
+    if ((rc = stpbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
+    BCN_HIP(hipMemset(stpbuf.p, 0, stpbuf.bytes));
+    stp = a.stp = static_cast<int32_t*>(stpbuf.p);
+    return BCN_OK;
+  }
+  ~Env1D() override {
+    DeviceGuard g(device);
+    fields.release(); a_last.release(); a_prev.release(); stpbuf.release();
+  }
+  size_t state_elems() const override { return (size_t)nfields * a.n; }
+  int copy_state(void* buf, int is_device, hipStream_t s, bool out) {
+    const size_t row = (size_t)a.n * sizeof(real);
+    real* f = static_cast<real*>(fields.p);
+    for (int k = 0; k < nfields; k++) {
+      char* ext = static_cast<char*>(buf) + (size_t)k * row;
+      real* dev = f + (size_t)k * batch * a.n;
+      hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+      if (out) BCN_HIP(hipMemcpy2DAsync(ext, nfields * row, dev, row, row, batch, kind, s));
+      else BCN_HIP(hipMemcpy2DAsync(dev, row, ext, nfields * row, row, batch, kind, s));
+    }
+    if (!is_device) BCN_HIP(hipStreamSynchronize(s));
+    return BCN_OK;
+  }
+  int get_state(void* buf, int is_device, hipStream_t s) override { return copy_state(buf, is_device, s, true); }
+  int set_state(const void* buf, int is_device, hipStream_t s) override {
+    return copy_state(const_cast<void*>(buf), is_device, s, false);
+  }
+  const char* kernel_name() const override { return kname; }
+};
+
+template <typename real>
+int make_burgers(const bcn_burgers_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  auto* e = new (std::nothrow) Env1D<real>();
+  if (!e) { bcn_set_error("out of host memory"); return BCN_ERR_ARG; }
+  e->kind = BCN_BURGERS; e->batch = batch; e->dtype = dtype; e->device = device; e->esz = sizeof(real);
+  e->nfields = 3; e->kname = "burgers_step_k";
+  Env1DArgs<real>& a = e->a;
+  a.n = a.nx = c->nx; a.ndt_act = c->ndt_act; a.n_act = c->n_act; a.n_obs = c->n_obs_pts;
+  a.ctrl_pos = c->ctrl_pos; a.n_obs_pts = c->n_obs_pts;
+  a.u_target = (real)c->u_target; a.amp = (real)c->amp;
+  a.dx = (real)c->dx; a.rdx = (real)(1.0 / c->dx); a.dt = (real)c->dt;
+  e->n_obs = c->n_obs_pts; e->n_act = 1;
+  int rc = e->init(1);
+  if (rc) { delete e; return rc; }
+  *out = e;
+  return BCN_OK;
+}
+
+template <typename real>
+int make_shkadov(const bcn_shkadov_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  auto* e = new (std::nothrow) Env1D<real>();
+  if (!e) { bcn_set_error("out of host memory"); return BCN_ERR_ARG; }
+  e->kind = BCN_SHKADOV; e->batch = batch; e->dtype = dtype; e->device = device; e->esz = sizeof(real);
+  e->nfields = 4; e->kname = "shkadov_step_k";
+  Env1DArgs<real>& a = e->a;
+  a.n = a.nx = c->nx; a.ndt_act = c->ndt_act; a.n_act = c->n_act; a.n_obs = c->n_obs * c->n_jets;
+  a.n_jets = c->n_jets; a.jet_pos = c->jet_pos; a.jet_hw = c->jet_hw; a.jet_space = c->jet_space;
+  a.l_obs = c->l_obs; a.l_rwd = c->l_rwd; a.n_obs_jet = c->n_obs; a.obs_stride = c->obs_stride;
+  a.n_interp = c->n_interp;
+  a.delta_p = (real)(1.0 / (5.0 * c->delta));
+  a.jet_amp = (real)c->jet_amp; a.eps = (real)c->eps; a.h_blow = (real)c->h_blow;
+  a.blowup_rwd = (real)c->blowup_rwd;
+  a.dx = (real)c->dx; a.rdx = (real)(1.0 / c->dx); a.dt = (real)c->dt;
+  e->n_obs = a.n_obs; e->n_act = c->n_jets;
+  int rc = e->init(c->n_jets);
+  if (rc) { delete e; return rc; }
+  *out = e;
+  return BCN_OK;
+}
+
+template <typename real>
+int make_sloshing(const bcn_sloshing_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  auto* e = new (std::nothrow) Env1D<real>();
+  if (!e) { bcn_set_error("out of host memory"); return BCN_ERR_ARG; }
+  e->kind = BCN_SLOSHING; e->batch = batch; e->dtype = dtype; e->device = device; e->esz = sizeof(real);
+  e->nfields = 4; e->kname = "sloshing_step_k";
+  Env1DArgs<real>& a = e->a;
+  a.nx = c->nx; a.n = c->nx + 2; a.ndt_act = c->ndt_act; a.n_act = c->n_act;
+  a.n_obs = c->nx / 2 + (c->nx % 2 ? 1 : 0);
+  a.n_interp = c->n_interp;
+  a.g = (real)c->g; a.amp = (real)c->amp; a.alpha = (real)c->alpha;
+  a.dx = (real)c->dx; a.rdx = (real)(1.0 / c->dx); a.dt = (real)c->dt;
+  e->n_obs = a.n_obs; e->n_act = 1;
+  int rc = e->init(1);
+  if (rc) { delete e; return rc; }
+  *out = e;
+  return BCN_OK;
+}
+
+int check_create(const void* cfg, int batch, int dtype, int device, bcn_env_t* out) {
+  if (!cfg || !out) { bcn_set_error("null cfg/out"); return BCN_ERR_ARG; }
+  if (batch <= 0) { bcn_set_error("batch must be > 0"); return BCN_ERR_ARG; }
+  if (dtype != BCN_F32 && dtype != BCN_F64) { bcn_set_error("dtype must be BCN_F32 or BCN_F64"); return BCN_ERR_ARG; }
+  int ndev = 0;
+  BCN_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { bcn_set_error("device %d out of range (%d visible)", device, ndev); return BCN_ERR_ARG; }
+  return BCN_OK;
+}
+
+#define BCN_CHECK_KIND(h, K)                                                        \
+  if (!(h) || (h)->kind != (K)) { bcn_set_error("handle is not a " #K " env"); return BCN_ERR_ARG; }
+
+template <typename real>
+static int ns2d_reset_t(bcn_env_t h, const void* init, void* obs, void* stream) {
+  auto* e = static_cast<NS2DEnv<real>*>(h);
+  DeviceGuard g(e->device);
+  NS2DArgs<real> a = e->a;
+  a.init_fields = static_cast<const real*>(init);
+  a.obs_out = static_cast<real*>(obs);
+  return ns2d_launch_reset<real>(a, e->batch, static_cast<hipStream_t>(stream));
+}
+
+template <typename real>
+static int ns2d_step_t(bcn_env_t h, const void* actions, const int32_t* iactions, void* actions_norm, void* obs,
+                       void* rwd, uint8_t* done, uint8_t* trunc, int32_t* status, int32_t* sweeps, void* stream) {
+  auto* e = static_cast<NS2DEnv<real>*>(h);
+  DeviceGuard g(e->device);
+  NS2DArgs<real>& a = e->a;
+  a.actions = static_cast<const real*>(actions);
+  a.iactions = iactions;
+  a.actions_norm = static_cast<real*>(actions_norm);
+  a.obs_out = static_cast<real*>(obs);
+  a.rwd_out = static_cast<real*>(rwd);
+  a.done = done; a.trunc = trunc; a.status = status; a.sweeps = sweeps;
+  return e->launch(static_cast<hipStream_t>(stream));
+}
+
+template <typename real>
+static Env1DArgs<real>& env1d_io(bcn_env_t h, const void* actions, const void* noise, const void* init, void* obs,
+                                 void* rwd, uint8_t* done, uint8_t* trunc, int32_t* status) {
+  auto* e = static_cast<Env1D<real>*>(h);
+  Env1DArgs<real>& a = e->a;
+  a.actions = static_cast<const real*>(actions);
+  a.noise = static_cast<const real*>(noise);
+  a.init_fields = static_cast<const real*>(init);
+  a.obs_out = static_cast<real*>(obs);
+  a.rwd_out = static_cast<real*>(rwd);
+  a.done = done; a.trunc = trunc; a.status = status;
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- rayleigh --------------------------------------------------------------------------------
+int bcn_rayleigh_create(const bcn_rayleigh_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  int rc = check_create(c, batch, dtype, device, out);
+  if (rc) return rc;
+  if (c->nx < 2 || c->ny < 2 || c->n_sgts < 1 || c->n_sgts > 64 || c->nx_sgts < 1 || c->ndt_act < 0) {
+    bcn_set_error("rayleigh cfg out of range (nx,ny >= 2; 1 <= n_sgts <= 64)");
+    return BCN_ERR_ARG;
+  }
+  DeviceGuard g(device);
+  return dtype == BCN_F32 ? make_rayleigh<float>(c, batch, dtype, device, out)
+                          : make_rayleigh<double>(c, batch, dtype, device, out);
+}
+
+int bcn_rayleigh_reset(bcn_env_t h, const void* init_fields_dev, void* obs_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_RAYLEIGH);
+  return h->dtype == BCN_F32 ? ns2d_reset_t<float>(h, init_fields_dev, obs_dev, stream)
+                             : ns2d_reset_t<double>(h, init_fields_dev, obs_dev, stream);
+}
+
+int bcn_rayleigh_step(bcn_env_t h, const void* actions_dev, void* actions_norm_dev, void* obs_dev, void* rwd_dev,
+                      uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev, int32_t* sweeps_dev,
+                      void* stream) {
+  BCN_CHECK_KIND(h, BCN_RAYLEIGH);
+  return h->dtype == BCN_F32
+             ? ns2d_step_t<float>(h, actions_dev, nullptr, actions_norm_dev, obs_dev, rwd_dev, done_dev, trunc_dev,
+                                  status_dev, sweeps_dev, stream)
+             : ns2d_step_t<double>(h, actions_dev, nullptr, actions_norm_dev, obs_dev, rwd_dev, done_dev, trunc_dev,
+                                   status_dev, sweeps_dev, stream);
+}
+
+// ---- mixing ----------------------------------------------------------------------------------
+int bcn_mixing_create(const bcn_mixing_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  int rc = check_create(c, batch, dtype, device, out);
+  if (rc) return rc;
+  if (c->nx < 2 || c->ny < 2 || c->ndt_act < 0) { bcn_set_error("mixing cfg out of range"); return BCN_ERR_ARG; }
+  DeviceGuard g(device);
+  return dtype == BCN_F32 ? make_mixing<float>(c, batch, dtype, device, out)
+                          : make_mixing<double>(c, batch, dtype, device, out);
+}
+
+int bcn_mixing_reset(bcn_env_t h, void* obs_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_MIXING);
+  return h->dtype == BCN_F32 ? ns2d_reset_t<float>(h, nullptr, obs_dev, stream)
+                             : ns2d_reset_t<double>(h, nullptr, obs_dev, stream);
+}
+
+int bcn_mixing_step(bcn_env_t h, const int32_t* actions_dev, void* obs_dev, void* rwd_dev, uint8_t* done_dev,
+                    uint8_t* trunc_dev, int32_t* status_dev, int32_t* sweeps_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_MIXING);
+  return h->dtype == BCN_F32
+             ? ns2d_step_t<float>(h, nullptr, actions_dev, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+                                  status_dev, sweeps_dev, stream)
+             : ns2d_step_t<double>(h, nullptr, actions_dev, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+                                   status_dev, sweeps_dev, stream);
+}
+
+// ---- 1D envs ---------------------------------------------------------------------------------
+#define BCN_1D_CALL(h, FN, ...)                                                                       \
+  (h->dtype == BCN_F32 ? FN<float>(env1d_io<float>(h, __VA_ARGS__), h->batch, static_cast<hipStream_t>(stream)) \
+                       : FN<double>(env1d_io<double>(h, __VA_ARGS__), h->batch, static_cast<hipStream_t>(stream)))
+
+int bcn_burgers_create(const bcn_burgers_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  int rc = check_create(c, batch, dtype, device, out);
+  if (rc) return rc;
+  if (c->nx < 8 || c->nx > 8192 || c->ctrl_pos < c->n_obs_pts || c->ctrl_pos >= c->nx || c->n_obs_pts > 64) {
+    bcn_set_error("burgers cfg out of range (8 <= nx <= 8192, n_obs_pts <= ctrl_pos < nx)");
+    return BCN_ERR_ARG;
+  }
+  DeviceGuard g(device);
+  return dtype == BCN_F32 ? make_burgers<float>(c, batch, dtype, device, out)
+                          : make_burgers<double>(c, batch, dtype, device, out);
+}
+int bcn_burgers_reset(bcn_env_t h, void* obs_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_BURGERS);
+  DeviceGuard g(h->device);
+  return BCN_1D_CALL(h, burgers_launch_reset, nullptr, nullptr, nullptr, obs_dev, nullptr, nullptr, nullptr, nullptr);
+}
+int bcn_burgers_step(bcn_env_t h, const void* actions_dev, const void* noise_dev, void* obs_dev, void* rwd_dev,
+                     uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_BURGERS);
+  DeviceGuard g(h->device);
+  return BCN_1D_CALL(h, burgers_launch_step, actions_dev, noise_dev, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+                     status_dev);
+}
+
+int bcn_shkadov_create(const bcn_shkadov_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  int rc = check_create(c, batch, dtype, device, out);
+  if (rc) return rc;
+  const int last = c->jet_pos + (c->n_jets - 1) * c->jet_space;
+  if (c->nx < 16 || c->nx > 8192 || c->n_jets < 1 || c->n_jets > 64 || 2 * c->jet_hw >= c->jet_space ||
+      c->jet_pos - c->l_obs < 0 || c->jet_pos - c->jet_hw < 1 || last + c->l_rwd > c->nx ||
+      last + c->jet_hw > c->nx - 2 || c->n_interp < 1) {
+    bcn_set_error("shkadov cfg out of range (16 <= nx <= 8192, 1 <= n_jets <= 64, non-overlapping jets inside the domain)");
+    return BCN_ERR_ARG;
+  }
+  DeviceGuard g(device);
+  return dtype == BCN_F32 ? make_shkadov<float>(c, batch, dtype, device, out)
+                          : make_shkadov<double>(c, batch, dtype, device, out);
+}
+int bcn_shkadov_reset(bcn_env_t h, const void* init_fields_dev, void* obs_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_SHKADOV);
+  DeviceGuard g(h->device);
+  return BCN_1D_CALL(h, shkadov_launch_reset, nullptr, nullptr, init_fields_dev, obs_dev, nullptr, nullptr, nullptr,
+                     nullptr);
+}
+int bcn_shkadov_step(bcn_env_t h, const void* actions_dev, const void* noise_dev, void* obs_dev, void* rwd_dev,
+                     uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_SHKADOV);
+  DeviceGuard g(h->device);
+  return BCN_1D_CALL(h, shkadov_launch_step, actions_dev, noise_dev, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+                     status_dev);
+}
+
+int bcn_sloshing_create(const bcn_sloshing_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
+  int rc = check_create(c, batch, dtype, device, out);
+  if (rc) return rc;
+  if (c->nx < 4 || c->nx + 2 > 8192 || c->n_interp < 1) { bcn_set_error("sloshing cfg out of range"); return BCN_ERR_ARG; }
+  DeviceGuard g(device);
+  return dtype == BCN_F32 ? make_sloshing<float>(c, batch, dtype, device, out)
+                          : make_sloshing<double>(c, batch, dtype, device, out);
+}
+int bcn_sloshing_reset(bcn_env_t h, const void* init_fields_dev, void* obs_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_SLOSHING);
+  DeviceGuard g(h->device);
+  return BCN_1D_CALL(h, sloshing_launch_reset, nullptr, nullptr, init_fields_dev, obs_dev, nullptr, nullptr, nullptr,
+                     nullptr);
+}
+int bcn_sloshing_step(bcn_env_t h, const void* actions_dev, void* obs_dev, void* rwd_dev, uint8_t* done_dev,
+                      uint8_t* trunc_dev, int32_t* status_dev, void* stream) {
+  BCN_CHECK_KIND(h, BCN_SLOSHING);
+  DeviceGuard g(h->device);
+  return BCN_1D_CALL(h, sloshing_launch_step, actions_dev, nullptr, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+                     status_dev);
+}
+
+// ---- common ----------------------------------------------------------------------------------
+int bcn_env_kind(bcn_env_t h) { return h ? h->kind : -1; }
+int bcn_batch(bcn_env_t h) { return h ? h->batch : 0; }
+int bcn_dtype(bcn_env_t h) { return h ? h->dtype : -1; }
+int bcn_n_obs(bcn_env_t h) { return h ? h->n_obs : 0; }
+int bcn_n_act(bcn_env_t h) { return h ? h->n_act : 0; }
+size_t bcn_state_elems(bcn_env_t h) { return h ? h->state_elems() : 0; }
+
+int bcn_get_state(bcn_env_t h, void* buf, int is_device, void* stream) {
+  if (!h || !buf) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
+  DeviceGuard g(h->device);
+  return h->get_state(buf, is_device, static_cast<hipStream_t>(stream));
+}
+int bcn_set_state(bcn_env_t h, const void* buf, int is_device, void* stream) {
+  if (!h || !buf) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
+  DeviceGuard g(h->device);
+  return h->set_state(buf, is_device, static_cast<hipStream_t>(stream));
+}
+int bcn_get_stp(bcn_env_t h, int32_t* buf_host, void* stream) {
+  if (!h || !buf_host) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
+  DeviceGuard g(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  BCN_HIP(hipMemcpyAsync(buf_host, h->stp, (size_t)h->batch * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  BCN_HIP(hipStreamSynchronize(s));
+  return BCN_OK;
+}
+int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream) {
+  if (!h || !buf_host) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
+  DeviceGuard g(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  BCN_HIP(hipMemcpyAsync(h->stp, buf_host, (size_t)h->batch * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  BCN_HIP(hipStreamSynchronize(s));
+  return BCN_OK;
+}
+int bcn_set_variant(bcn_env_t h, int variant) { return h ? h->set_variant(variant) : 0; }
+const char* bcn_kernel_name(bcn_env_t h) { return h ? h->kernel_name() : ""; }
+int bcn_destroy(bcn_env_t h) {
+  if (!h) return BCN_OK;
+  {
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+  }
+  delete h;
+  return BCN_OK;
+}
+const char* bcn_last_error(void) { return g_err; }
+const char* bcn_version(void) { return "beacon_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// ns2d.h -- argument block shared by the rayleigh / mixing kernels (2D incompressible
+// Navier-Stokes fractional step on a MAC grid).
+//
+// HBM layout: every field is [B][ny+2][nx+2], x fastest (the transpose, per replica, of the
+// reference's [nx+2][ny+2] arrays): F(i,j) = f[b*ncell + j*sx + i], ghosts at 0 and n+1.
+#pragma once
+#include "bcn_common.h"
+
+template <typename real>
+struct NS2DArgs {
+  int nx, ny, sx, ncell;
+  int ndt_act, n_act, itmax;
+  int kind;  // 0 rayleigh, 1 mixing
+  int n_sgts, nx_sgts;
+  int nxo, nyo, nx_obs, ny_obs, n_obs_steps, n_obs;
+  int i_min, i_max, j_min, j_max;  // mixing patch
+  real dt, rdx, rdy, rdx2, rdy2;
+  real kmom;  // sqrt(pr/ra)   | 1/re
+  real ksc;   // 1/sqrt(pr*ra) | 1/pe
+  real cx, cy, cb;  // Jacobi: phi = cx (E+W) + cy (N+S) - cb * div(us,vs)
+  real tol;
+  real Tc, Th, C, u_max, ref_c, C0;
+  real rwd_scale;  // rayleigh: 1 / (0.5 dy nx)
+  // persistent device state
+  real *u, *v, *p, *S, *us, *vs;
+  real *g0, *g1, *g2;  // per-replica global work arrays (used when they do not fit LDS)
+  real* obs_hist;      // [B][n_obs]
+  real* a_last;        // rayleigh [B][n_sgts]
+  int32_t* ia_last;    // mixing [B]
+  int32_t* stp;
+  // per-call I/O
+  const real* actions;
+  const int32_t* iactions;
+  real* actions_norm;
+  real* obs_out;
+  real* rwd_out;
+  uint8_t* done;
+  uint8_t* trunc;
+  int32_t* status;
+  int32_t* sweeps;
+  const real* init_fields;  // reset only
+  int work_in_lds;
+};
+
+// launchers (one per translation unit)
+template <typename real> int ns2d_launch_generic(const NS2DArgs<real>& a, int batch, hipStream_t s);
+template <typename real> int ns2d_launch_reset(const NS2DArgs<real>& a, int batch, hipStream_t s);
+size_t ns2d_generic_lds_bytes(int ncell, size_t esz);
+// register-resident CDNA4 path (ns2d_fast.hip); returns BCN_ERR_UNSUPPORTED when the grid has none
+template <typename real> bool ns2d_fast_supported(const NS2DArgs<real>& a);
+template <typename real> int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s);

@@ -1,0 +1,461 @@
+"""Batched (vectorised) envs: B independent replicas of one beacon env advanced by one HIP
+launch per step().  Same reset()/step() surface as the reference's Gym classes, with a
+leading batch dimension; tensors stay on the GPU (torch is only the allocator / stream
+provider -- all arithmetic happens in libbeacon_hip.so).
+
+Derived parameters are computed exactly as the reference constructors do (citations are
+file:line into /root/reference/beacon/)."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {"f32": (torch.float32, _lib.F32), "f64": (torch.float64, _lib.F64),
+       "float32": (torch.float32, _lib.F32), "float64": (torch.float64, _lib.F64),
+       torch.float32: (torch.float32, _lib.F32), torch.float64: (torch.float64, _lib.F64)}
+
+
+class Box(object):
+    """Stand-in for gymnasium.spaces.Box (gymnasium is optional)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape).copy()
+        self.shape, self.dtype = tuple(shape), dtype
+
+    def sample(self, rng=None):
+        rng = rng or np.random.default_rng()
+        return rng.uniform(self.low, self.high).astype(self.dtype)
+
+
+class Discrete(object):
+    def __init__(self, n):
+        self.n, self.shape, self.dtype = n, (), np.int64
+
+    def sample(self, rng=None):
+        rng = rng or np.random.default_rng()
+        return int(rng.integers(0, self.n))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class VecEnv(object):
+    """Common machinery.  Subclasses set self.cfg and implement _create/_reset/_step."""
+
+    action_is_int = False
+    needs_noise = False
+
+    def __init__(self, batch, device="cuda:0", dtype="f32"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("beacon_amd needs a ROCm GPU: the solver path is HIP-only (no CPU fallback)")
+        self.lib = _lib.load()
+        self.batch = int(batch)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (ROCm) device")
+        self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.dev_index)
+        self.tdtype, self.cdtype = _DT[dtype]
+        self.h = C.c_void_p()
+        self._create()
+        self.n_obs = self.lib.bcn_n_obs(self.h)
+        self.n_actions = self.lib.bcn_n_act(self.h)
+        B = self.batch
+        self.obs = torch.zeros((B, self.n_obs), dtype=self.tdtype, device=self.device)
+        self.rwd = torch.zeros((B,), dtype=self.tdtype, device=self.device)
+        self.done = torch.zeros((B,), dtype=torch.uint8, device=self.device)
+        self.trunc = torch.zeros((B,), dtype=torch.uint8, device=self.device)
+        self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _real(self, x, shape):
+        """actions / noise / init fields -> contiguous device tensor of the env dtype."""
+        if x is None:
+            return None
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float64))
+        x = x.to(device=self.device, dtype=self.tdtype).reshape(shape).contiguous()
+        return x
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.bcn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ------------------------------------------------------------------------------
+    def state_shape(self):
+        raise NotImplementedError
+
+    def get_state(self):
+        """Solver fields of every replica as one device tensor (layout: include/beacon_hip.h)."""
+        out = torch.empty((self.batch,) + self.state_shape(), dtype=self.tdtype, device=self.device)
+        _lib.check(self.lib.bcn_get_state(self.h, _ptr(out), 1, self._stream()))
+        return out
+
+    def set_state(self, state):
+        st = self._real(state, (self.batch,) + self.state_shape())
+        _lib.check(self.lib.bcn_set_state(self.h, _ptr(st), 1, self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()  # `st` may be a temporary
+
+    def get_stp(self):
+        buf = (C.c_int32 * self.batch)()
+        _lib.check(self.lib.bcn_get_stp(self.h, buf, self._stream()))
+        return np.frombuffer(buf, dtype=np.int32).copy()
+
+    def set_stp(self, stp):
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(stp, dtype=np.int32), (self.batch,)))
+        _lib.check(self.lib.bcn_set_stp(self.h, arr.ctypes.data_as(_lib.c_i32p), self._stream()))
+
+    def set_variant(self, v):
+        return self.lib.bcn_set_variant(self.h, int(v))
+
+    @property
+    def kernel_name(self):
+        return self.lib.bcn_kernel_name(self.h).decode()
+
+    def check_status(self):
+        """Synchronise and raise if any replica reported a solver failure (the reference
+        prints and exit(1)s on Poisson non-convergence: rayleigh.py:221-224)."""
+        st = self.status.cpu().numpy()
+        if (st & _lib.ST_ITMAX).any():
+            bad = np.nonzero(st & _lib.ST_ITMAX)[0]
+            raise RuntimeError("Exceeded max number of iterations in solver (replicas %s)" % bad[:8].tolist())
+        return st
+
+    # -- Gym surface ------------------------------------------------------------------------
+    def reset(self):
+        self._reset()
+        return self.obs, None
+
+    def step(self, actions=None, noise=None):
+        self._step(actions, noise)
+        return self.obs, self.rwd, self.done, self.trunc, None
+
+
+# ---------------------------------------------------------------------------------------------
+class VecRayleigh(VecEnv):
+    """rayleigh/rayleigh.py:16-366.  `init_fields`: [4, nx+2, ny+2] in the reference's [i, j]
+    layout (u, v, p, T) -- what load() parses from init_field.dat (:356-362) -- or None
+    (init=False: all-zero fields)."""
+
+    def __init__(self, batch, device="cuda:0", dtype="f32", init_fields=None,
+                 L=1.0, H=1.0, n_sgts=10, ra=1.0e4):
+        self._derive(L, H, n_sgts, ra)
+        self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
+        super().__init__(batch, device, dtype)
+        self._post_init()
+
+    def _derive(self, L=1.0, H=1.0, n_sgts=10, ra=1.0e4):
+        self.L, self.H, self.ra, self.n_sgts = L, H, ra, n_sgts
+        self.nx, self.ny = int(50 * L), int(50 * H)                       # :26-27
+        self.pr, self.Tc, self.Th, self.C = 0.71, -0.5, 0.5, 0.75         # :29-32
+        self.dt, self.dt_act, self.t_warmup, self.t_act = 0.01, 2.0, 200.0, 200.0
+        self.nx_obs_pts, self.ny_obs_pts, self.n_obs_steps = 4 * int(L), 4 * int(H), 4
+        self.dx, self.dy = float(L / self.nx), float(H / self.ny)         # :45-46
+        self.ndt_act = int(self.dt_act / self.dt)                         # :48
+        self.n_act = int(self.t_act / self.dt_act)                        # :50
+        self.n_warmup = int(self.t_warmup / self.dt_act)
+        self.nx_sgts = self.nx // n_sgts                                  # :52
+        self.n_obs_tot = 3 * self.n_obs_steps * self.nx_obs_pts * self.ny_obs_pts
+        self.nx_obs, self.ny_obs = self.nx // self.nx_obs_pts, self.ny // self.ny_obs_pts
+        self.tol, self.itmax = 1.0e-8, 300000                             # :414-417
+        return self
+
+    def _post_init(self):
+        n_sgts = self.n_sgts
+        self.action_space = Box(-self.C, self.C, (n_sgts,))
+        self.observation_space = Box(-1.0, 1.0, (self.n_obs_tot,))
+        self.actions_norm = torch.zeros((self.batch, n_sgts), dtype=self.tdtype, device=self.device)
+        self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)
+        self._init_dev = None
+        if self._init_np is not None:
+            assert self._init_np.shape == (4, self.nx + 2, self.ny + 2)
+            # reference arrays are [i, j]; the device layout is [j, i] (x fastest)
+            self._init_dev = self._real(np.ascontiguousarray(self._init_np.transpose(0, 2, 1)),
+                                        (4, self.ny + 2, self.nx + 2))
+
+    def _create(self):
+        c = _lib.RayleighCfg(nx=self.nx, ny=self.ny, ndt_act=self.ndt_act, n_act=self.n_act,
+                             n_sgts=self.n_sgts, nx_sgts=self.nx_sgts, nx_obs_pts=self.nx_obs_pts,
+                             ny_obs_pts=self.ny_obs_pts, nx_obs=self.nx_obs, ny_obs=self.ny_obs,
+                             n_obs_steps=self.n_obs_steps, itmax=self.itmax, dx=self.dx, dy=self.dy,
+                             dt=self.dt, pr=self.pr, ra=self.ra, Tc=self.Tc, Th=self.Th, C=self.C,
+                             tol=self.tol)
+        self.cfg = c
+        _lib.check(self.lib.bcn_rayleigh_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
+                                                C.byref(self.h)))
+
+    def set_ndt_act(self, n):
+        """Test hook: shorten the action step (the goldens for big grids use ndt_act=5)."""
+        self.close()
+        self.ndt_act = int(n)
+        self.h = C.c_void_p()
+        self._create()
+        self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)
+
+    def state_shape(self):
+        return (4, self.ny + 2, self.nx + 2)
+
+    def _reset(self):
+        _lib.check(self.lib.bcn_rayleigh_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))
+
+    def _step(self, actions, noise=None):
+        a = self._real(actions, (self.batch, self.n_sgts))
+        self._keep = a
+        _lib.check(self.lib.bcn_rayleigh_step(self.h, _ptr(a), _ptr(self.actions_norm), _ptr(self.obs),
+                                              _ptr(self.rwd), _ptr(self.done), _ptr(self.trunc),
+                                              _ptr(self.status), _ptr(self.sweeps), self._stream()))
+
+
+class VecMixing(VecEnv):
+    """mixing/mixing.py:16-378"""
+
+    action_is_int = True
+
+    def __init__(self, batch, device="cuda:0", dtype="f32", L=1.0, H=1.0, re=100.0, pe=10000.0,
+                 side=0.5, C0=1.0):
+        self._derive(L, H, re, pe, side, C0)
+        super().__init__(batch, device, dtype)
+        self.action_space = Discrete(4)
+        self.observation_space = Box(-1.0, 1.0, (self.n_obs_tot,))
+        self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)
+
+    def _derive(self, L=1.0, H=1.0, re=100.0, pe=10000.0, side=0.5, C0=1.0):
+        self.L, self.H, self.re, self.pe, self.side, self.C0 = L, H, re, pe, side, C0
+        self.nx, self.ny = int(100 * L), int(100 * H)                    # :27-28
+        self.nu = 0.01
+        self.u_max = re * self.nu / L                                    # :34
+        self.dt, self.dt_act, self.t_act = 0.002, 0.5, 50.0
+        self.nx_obs_pts, self.ny_obs_pts, self.n_obs_steps = 4 * int(L), 4 * int(H), 4
+        self.dx, self.dy = float(L / self.nx), float(H / self.ny)
+        self.ndt_act = int(self.dt_act / self.dt)
+        self.n_act = int(self.t_act / self.dt_act)
+        self.n_obs_tot = 3 * self.n_obs_steps * self.nx_obs_pts * self.ny_obs_pts
+        self.nx_obs, self.ny_obs = self.nx // self.nx_obs_pts, self.ny // self.ny_obs_pts
+        self.tol, self.itmax = 1.0e-4, 300000                            # :423-426
+        self.i_min = math.floor(0.5 * (L - side) / self.dx)              # :90-93
+        self.i_max = self.i_min + math.floor(side / self.dx)
+        self.j_min = math.floor(0.5 * (H - side) / self.dy)
+        self.j_max = self.j_min + math.floor(side / self.dy)
+        return self
+
+    def _create(self):
+        c = _lib.MixingCfg(nx=self.nx, ny=self.ny, ndt_act=self.ndt_act, n_act=self.n_act,
+                           nx_obs_pts=self.nx_obs_pts, ny_obs_pts=self.ny_obs_pts, nx_obs=self.nx_obs,
+                           ny_obs=self.ny_obs, n_obs_steps=self.n_obs_steps, itmax=self.itmax,
+                           i_min=self.i_min, i_max=self.i_max, j_min=self.j_min, j_max=self.j_max,
+                           dx=self.dx, dy=self.dy, dt=self.dt, re=self.re, pe=self.pe, u_max=self.u_max,
+                           C0=self.C0, ref_c=(self.side * self.side) / (self.L * self.H) * self.C0,
+                           tol=self.tol)
+        self.cfg = c
+        _lib.check(self.lib.bcn_mixing_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
+                                              C.byref(self.h)))
+
+    def set_ndt_act(self, n):
+        self.close()
+        self.ndt_act = int(n)
+        self.h = C.c_void_p()
+        self._create()
+        self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)
+
+    def state_shape(self):
+        return (4, self.ny + 2, self.nx + 2)
+
+    def _reset(self):
+        _lib.check(self.lib.bcn_mixing_reset(self.h, _ptr(self.obs), self._stream()))
+
+    def _step(self, actions, noise=None):
+        a = None
+        if actions is not None:
+            if not torch.is_tensor(actions):
+                actions = torch.as_tensor(np.asarray(actions, dtype=np.int64))
+            a = actions.to(device=self.device, dtype=torch.int32).reshape(self.batch).contiguous()
+        self._keep = a
+        _lib.check(self.lib.bcn_mixing_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.rwd), _ptr(self.done),
+                                            _ptr(self.trunc), _ptr(self.status), _ptr(self.sweeps),
+                                            self._stream()))
+
+
+class VecBurgers(VecEnv):
+    """burgers/burgers.py:17-227.  `nx` is a kwarg here (a literal 500 in the reference, :26)."""
+
+    needs_noise = True
+
+    def __init__(self, batch, device="cuda:0", dtype="f32", u_target=0.5, amp=10.0, sigma=0.1,
+                 ctrl_pos=1.0, L=2.0, nx=500, seed=0):
+        self._derive(u_target, amp, sigma, ctrl_pos, L, nx)
+        super().__init__(batch, device, dtype)
+        self.action_space = Box(-1.0, 1.0, (1,))
+        self.observation_space = Box(0.0, 1.0, (self.n_obs_pts,))
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+
+    def _derive(self, u_target=0.5, amp=10.0, sigma=0.1, ctrl_pos=1.0, L=2.0, nx=500):
+        self.L, self.nx, self.amp, self.sigma, self.u_target = L, nx, amp, sigma, u_target
+        self.t_max, self.dt_act, self.n_obs_pts = 10.0, 0.05, 5
+        self.dx = float(L / nx)                                          # :36
+        self.ctrl_pos = int(ctrl_pos / self.dx)                          # :37
+        self.dt = 0.2 * self.dx                                          # :38
+        self.ndt_act = int(self.dt_act / self.dt)                        # :40
+        self.n_act = int(self.t_max / self.dt_act)                       # :42
+        return self
+
+    def _create(self):
+        c = _lib.BurgersCfg(nx=self.nx, ndt_act=self.ndt_act, n_act=self.n_act, ctrl_pos=self.ctrl_pos,
+                            n_obs_pts=self.n_obs_pts, dx=self.dx, dt=self.dt, amp=self.amp,
+                            u_target=self.u_target)
+        self.cfg = c
+        _lib.check(self.lib.bcn_burgers_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
+                                               C.byref(self.h)))
+
+    def state_shape(self):
+        return (3, self.nx)
+
+    def draw_noise(self):
+        """Device-side stand-in for np.random.uniform(-sigma, sigma, 1) (burgers.py:127)."""
+        r = torch.rand((self.batch,), generator=self.gen, device=self.device, dtype=self.tdtype)
+        return (2.0 * r - 1.0) * self.sigma
+
+    def _reset(self):
+        _lib.check(self.lib.bcn_burgers_reset(self.h, _ptr(self.obs), self._stream()))
+
+    def _step(self, actions, noise=None):
+        a = self._real(actions, (self.batch,))
+        nz = self.draw_noise() if noise is None else self._real(noise, (self.batch,))
+        self._keep = (a, nz)
+        _lib.check(self.lib.bcn_burgers_step(self.h, _ptr(a), _ptr(nz), _ptr(self.obs), _ptr(self.rwd),
+                                             _ptr(self.done), _ptr(self.trunc), _ptr(self.status),
+                                             self._stream()))
+
+
+class VecShkadov(VecEnv):
+    """shkadov/shkadov.py:16-372.  `init_fields`: [2, >=nx] (h_init, q_init) as load() parses
+    them (:364-368), or None for the flat film h=q=1."""
+
+    needs_noise = True
+
+    def __init__(self, batch, device="cuda:0", dtype="f32", init_fields=None, L0=150.0, n_jets=5,
+                 jet_pos=150.0, jet_space=10.0, delta=0.1, t_act=20.0, seed=0):
+        self._derive(L0, n_jets, jet_pos, jet_space, delta, t_act)
+        self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
+        super().__init__(batch, device, dtype)
+        self.action_space = Box(-1.0, 1.0, (n_jets,))
+        self.observation_space = Box(-1.0, 1.0, (self.n_obs * n_jets,))
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self._init_dev = None
+        if self._init_np is not None:
+            self._init_dev = self._real(np.ascontiguousarray(self._init_np[:, :self.nx]), (2, self.nx))
+
+    def _derive(self, L0=150.0, n_jets=5, jet_pos=150.0, jet_space=10.0, delta=0.1, t_act=20.0):
+        self.L = L0 + jet_space * (n_jets + 2)                           # :32
+        self.nx = int(5 * self.L)                                        # :33
+        self.dt, self.dt_act, self.t_act = 0.001, 0.05, t_act
+        self.sigma, self.delta, self.n_jets, self.jet_amp = 5.0e-4, delta, n_jets, 5.0
+        self.eps, self.blowup_rwd, self.h_max = 1.0e-8, -1.0, 5.0
+        self.dx = float(self.L / self.nx)                                # :56
+        self.ndt_act = int(self.dt_act / self.dt)
+        self.n_act = int(t_act / self.dt_act)
+        self.n_interp = int(0.02 / self.dt)                              # :63
+        self.jet_pos = int(jet_pos / self.dx)                            # :64
+        self.jet_hw = int(2.0 / self.dx)                                 # :65
+        self.jet_space = int(jet_space / self.dx)                        # :67
+        self.l_rwd = int(10.0 / self.dx)                                 # :70
+        self.n_obs = int(10.0)                                           # :71
+        self.l_obs = int(10.0 / self.dx)                                 # :72
+        self.obs_stride = int(1.0 / self.dx)                             # :245
+        return self
+
+    def _create(self):
+        c = _lib.ShkadovCfg(nx=self.nx, ndt_act=self.ndt_act, n_act=self.n_act, n_jets=self.n_jets,
+                            jet_pos=self.jet_pos, jet_hw=self.jet_hw, jet_space=self.jet_space,
+                            l_obs=self.l_obs, l_rwd=self.l_rwd, n_obs=self.n_obs,
+                            obs_stride=self.obs_stride, n_interp=self.n_interp, dx=self.dx, dt=self.dt,
+                            delta=self.delta, jet_amp=self.jet_amp, eps=self.eps,
+                            h_blow=5.0 * self.h_max, blowup_rwd=self.blowup_rwd)
+        self.cfg = c
+        _lib.check(self.lib.bcn_shkadov_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
+                                               C.byref(self.h)))
+
+    def state_shape(self):
+        return (4, self.nx)
+
+    def draw_noise(self):
+        r = torch.rand((self.batch, self.ndt_act), generator=self.gen, device=self.device, dtype=self.tdtype)
+        return (2.0 * r - 1.0) * self.sigma
+
+    def _reset(self):
+        _lib.check(self.lib.bcn_shkadov_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))
+
+    def _step(self, actions, noise=None):
+        a = self._real(actions, (self.batch, self.n_jets))
+        nz = self.draw_noise() if noise is None else self._real(noise, (self.batch, self.ndt_act))
+        self._keep = (a, nz)
+        _lib.check(self.lib.bcn_shkadov_step(self.h, _ptr(a), _ptr(nz), _ptr(self.obs), _ptr(self.rwd),
+                                             _ptr(self.done), _ptr(self.trunc), _ptr(self.status),
+                                             self._stream()))
+
+
+class VecSloshing(VecEnv):
+    """sloshing/sloshing.py:16-320.  `init_fields`: [2, nx+2] (h_init, q_init incl. ghosts)."""
+
+    def __init__(self, batch, device="cuda:0", dtype="f32", init_fields=None, L=2.5, amp=5.0,
+                 alpha=0.0005, g=9.81):
+        self._derive(L, amp, alpha, g)
+        self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
+        super().__init__(batch, device, dtype)
+        self.action_space = Box(-1.0, 1.0, (1,))
+        self.observation_space = Box(-1.0, 1.0, (self.n_obs,))
+        self._init_dev = None
+        if self._init_np is not None:
+            self._init_dev = self._real(self._init_np, (2, self.nx + 2))
+
+    def _derive(self, L=2.5, amp=5.0, alpha=0.0005, g=9.81):
+        self.L, self.amp, self.alpha, self.g = L, amp, alpha, g
+        self.nx = int(80 * L)                                            # :24
+        self.dt, self.dt_act, self.t_warmup, self.t_act = 0.001, 0.05, 2.0, 10.0
+        self.dx = float(L / self.nx)
+        self.ndt_act = int(self.dt_act / self.dt)
+        self.n_act = int(self.t_act / self.dt_act)
+        self.n_warmup = int(self.t_warmup / self.dt_act)
+        self.n_interp = int(0.01 / self.dt)                              # :48
+        self.n_obs = self.nx // 2 + (1 if self.nx % 2 else 0)            # :39
+        return self
+
+    def _create(self):
+        c = _lib.SloshingCfg(nx=self.nx, ndt_act=self.ndt_act, n_act=self.n_act, n_interp=self.n_interp,
+                             dx=self.dx, dt=self.dt, g=self.g, amp=self.amp, alpha=self.alpha)
+        self.cfg = c
+        _lib.check(self.lib.bcn_sloshing_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
+                                                C.byref(self.h)))
+
+    def state_shape(self):
+        return (4, self.nx + 2)
+
+    @staticmethod
+    def signal(t, dt):
+        """Excitation used by the reference's warm-up generator (sloshing.py:134-138)."""
+        return 0.5 * (np.cos(np.pi * t) + 3.0 * np.cos(4.0 * np.pi * t))
+
+    def _reset(self):
+        _lib.check(self.lib.bcn_sloshing_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))
+
+    def _step(self, actions, noise=None):
+        a = self._real(actions, (self.batch,))
+        self._keep = a
+        _lib.check(self.lib.bcn_sloshing_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.rwd), _ptr(self.done),
+                                              _ptr(self.trunc), _ptr(self.status), self._stream()))

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: aggregate env steps/s of rayleigh-v0 (128x64 grid, batch 512 per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one batched env.step(): 200 solver timesteps (BCs, predictor, Jacobi pressure
+Poisson to the reference's tolerance, corrector, ordered scalar transport) + obs + reward for
+every replica, in ONE HIP launch per GPU; with N > 1 the per-step gather of obs/rwd/done to
+rank 0 (RCCL) is inside the timed region.  Weak scaling: 512 replicas per GPU.
+Inputs are synthetic and resident in HBM before the timed region: developed-flow initial
+state from tests/golden/rayleigh_128x64_init.npz (float64 oracle warm-up), actions from
+numpy.random.default_rng(1234 + rank).uniform(-1, 1), distinct per replica and step.
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(nx, ny, sweeps, esz):
+    """per interior cell 20 values per timestep + 3 values per Jacobi sweep."""
+    cells = nx * ny
+    ndt = sweeps.shape[1]
+    return float(cells) * esz * (20.0 * ndt * sweeps.shape[0] + 3.0 * float(sweeps.sum()))
+
+
+def cpu_baseline(init, acts, cfg_kw, seconds=15.0):
+    """The float64 scalar-C oracle ("port" of the reference's numba loops) on a bounded sample:
+    one env per host core, as many action steps as fit ~`seconds`."""
+    import ctypes as C
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    nenv = min(cores, acts.shape[1])
+    e = O.rayleigh(init=False, **cfg_kw)
+    n = (e.cfg.nx + 2) * (e.cfg.ny + 2)
+    st = np.zeros((nenv, 8, n))
+    st[:, :4] = init.reshape(1, 4, n)
+    nobs = e.n_obs_tot
+    obs = np.zeros((nenv, nobs))
+    rwd = np.zeros(nenv)
+    sw = np.zeros(nenv, dtype=np.int64)
+    L = O.lib()
+    done_steps, t0 = 0, time.perf_counter()
+    tot_sw = 0
+    while done_steps < acts.shape[0]:
+        a = np.ascontiguousarray(acts[done_steps, :nenv].astype(np.float64))
+        L.orc_ns2d_step_batch(C.byref(e.cfg), nenv, O.dp(st.reshape(-1)), O.dp(a.reshape(-1)), a.shape[1],
+                              O.dp(obs.reshape(-1)), O.dp(rwd), sw.ctypes.data_as(C.POINTER(C.c_int64)), cores)
+        done_steps += 1
+        tot_sw += int(sw.sum())
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": nenv * done_steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d action steps of the same workload (float64 C oracle, OpenMP over envs, "
+                      "%.1f s, %.1f Jacobi sweeps per timestep)" % (nenv, done_steps, dt,
+                                                                   tot_sw / max(1, nenv * done_steps * e.cfg.ndt_act))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="replicas per GPU")
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--variant", type=int, default=-1, help="-1 = best available, 0 = generic kernel")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N"
+                         % (args.gpus, world))
+    import torch.distributed as dist
+    from beacon_amd import vec as V
+    from beacon_amd.dist import ShardedVecEnv
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    L, H = 2.56, 1.28
+    z = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))
+    init = z["fields"]
+    B, K, W = args.batch, args.steps, args.warmup
+    env = V.VecRayleigh(B, dev, args.dtype, init, L=L, H=H)
+    if args.variant >= 0:
+        env.set_variant(args.variant)
+    senv = ShardedVecEnv(env)
+    acts_np = np.random.default_rng(1234 + rank).uniform(-1.0, 1.0, (W + K, B, env.n_sgts))
+    acts = torch.as_tensor(acts_np, dtype=env.tdtype, device=dev)
+    senv.reset()
+    sweeps_all = []
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        senv.step(acts[k], scattered=True)
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()
+        env.step(acts[W + k])                       # the one HIP launch of this step
+        ev[k][1].record()
+        sweeps_all.append(env.sweeps.clone())       # tiny device copy, for the roofline accounting
+        if world > 1:                                # trainer-facing gather, inside the timed region
+            senv.sh.gather("obs", env.obs), senv.sh.gather("rwd", env.rwd)
+            senv.sh.gather("done", env.done), senv.sh.gather("trunc", env.trunc)
+    sync()
+    elapsed = time.perf_counter() - t0
+    env.check_status()
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+
+    kern_ms = [s.elapsed_time(e) for s, e in ev]
+    esz = 4 if args.dtype == "f32" else 8
+    alg = [algorithmic_bytes(env.nx, env.ny, s.cpu().numpy(), esz) for s in sweeps_all]
+    mean_sw = float(np.mean([float(s.float().mean()) for s in sweeps_all]))
+    if rank == 0:
+        achieved = (sum(alg) / len(alg)) / (sum(kern_ms) / len(kern_ms) * 1e-3) / 1e9
+        out = {
+            "metric": "aggregate env steps/sec, rayleigh-v0 batch=512/GPU 128x64",
+            "value": world * B * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "rayleigh-v0 (BASELINE configs[3]): L=2.56 H=1.28 -> 128x64 MAC grid, "
+                                   "%d replicas per GPU, 200 timesteps per step, Jacobi to tol=1e-8" % B,
+                       "global_batch": world * B, "grid": [env.nx, env.ny], "ndt_act": env.ndt_act,
+                       "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world,
+                       "kernel": env.kernel_name},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": env.kernel_name, "avg_launch_ms": sum(kern_ms) / len(kern_ms),
+                         "algorithmic_bytes_per_launch": sum(alg) / len(alg),
+                         "note": "effective GB/s = SURVEY 8d algorithmic bytes / launch time; state stays "
+                                 "on-chip/L2 inside the launch, so this is not HBM traffic"},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(init, acts_np[W:], dict(L=L, H=H))
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

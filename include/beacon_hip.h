@@ -1,0 +1,176 @@
+/*
+ * beacon_hip.h -- C ABI of libbeacon_hip.so: the MI355X-native batched stepper that
+ * replaces the per-env solver hot path of jviquerat/beacon.
+ *
+ * The reference has no FFI: its boundary is a duck-typed Gym env class, one instance
+ * per env.  Each entry point below stands in for one method of that
+ * class, batched over B independent replicas, and cites the reference method it
+ * replaces (file:line into /root/reference/beacon/).  Plain C types only; every
+ * pointer named *_dev is a DEVICE pointer in the handle's dtype (BCN_F32 -> float,
+ * BCN_F64 -> double) unless a type is spelled out; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Calls on one handle must be serialised by the caller
+ * (the reference env is not thread-safe either).  No call blocks on the GPU except
+ * bcn_get_state/bcn_set_state with host pointers, and *_destroy.
+ *
+ * Return value: 0 = BCN_OK, otherwise a BCN_ERR_* code; bcn_last_error() gives text.
+ * Solver failures never exit the process (the reference does: rayleigh.py:221-224);
+ * they are reported per replica in status_dev (BCN_ST_* bits).
+ */
+#ifndef BEACON_HIP_H
+#define BEACON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCN_API __attribute__((visibility("default")))
+
+typedef struct bcn_env_s* bcn_env_t;
+
+enum { BCN_F32 = 0, BCN_F64 = 1 };
+enum { BCN_OK = 0, BCN_ERR_ARG = 1, BCN_ERR_HIP = 2, BCN_ERR_UNSUPPORTED = 3 };
+/* per-replica status word written by *_step */
+enum { BCN_ST_OK = 0, BCN_ST_ITMAX = 1, BCN_ST_BLOWUP = 2 };
+/* env kinds (bcn_env_kind) */
+enum { BCN_RAYLEIGH = 0, BCN_MIXING = 1, BCN_BURGERS = 2, BCN_SHKADOV = 3, BCN_SLOSHING = 4 };
+
+/* ---- rayleigh: rayleigh/rayleigh.py -------------------------------------------------- */
+/* ctor kwargs + the derived quantities of rayleigh.__init__ (rayleigh.py:20-56) */
+typedef struct {
+  int32_t nx, ny;                 /* int(50 L), int(50 H) */
+  int32_t ndt_act, n_act;         /* 200, 100 */
+  int32_t n_sgts, nx_sgts;        /* 10, nx // n_sgts */
+  int32_t nx_obs_pts, ny_obs_pts; /* 4 int(L), 4 int(H) */
+  int32_t nx_obs, ny_obs;         /* nx // nx_obs_pts, ny // ny_obs_pts */
+  int32_t n_obs_steps;            /* 4 */
+  int32_t itmax;                  /* 300000 (rayleigh.py:417) */
+  double dx, dy, dt;
+  double pr, ra, Tc, Th, C;       /* 0.71, 1e4, -0.5, 0.5, 0.75 */
+  double tol;                     /* 1e-8 (rayleigh.py:414) */
+} bcn_rayleigh_cfg;
+
+/* replaces rayleigh.__init__ (rayleigh.py:20-86); batch = number of replicas on this device */
+BCN_API int bcn_rayleigh_create(const bcn_rayleigh_cfg* cfg, int batch, int dtype, int device, bcn_env_t* out);
+/* replaces rayleigh.reset (rayleigh.py:89-128).  init_fields_dev: [4][ny+2][nx+2] (u,v,p,T; x fastest)
+ * shared by all replicas, or NULL for all-zero fields (init=False).  obs_dev[B][n_obs] may be NULL. */
+BCN_API int bcn_rayleigh_reset(bcn_env_t h, const void* init_fields_dev, void* obs_dev, void* stream);
+/* replaces rayleigh.step (rayleigh.py:138-157) incl. solve/get_obs/get_rwd (:160-275).
+ * actions_dev[B][n_sgts] raw actions, NULL = repeat last (a=None, :162); on return
+ * actions_norm_dev[B][n_sgts] (may be NULL) holds the conditioned actions the reference writes
+ * back into the caller's list (:165-168).  obs_dev[B][n_obs], rwd_dev[B], done_dev/trunc_dev
+ * uint8[B], status_dev int32[B], sweeps_dev int32[B][ndt_act] Jacobi sweeps per timestep (NULL ok). */
+BCN_API int bcn_rayleigh_step(bcn_env_t h, const void* actions_dev, void* actions_norm_dev, void* obs_dev,
+                      void* rwd_dev, uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev,
+                      int32_t* sweeps_dev, void* stream);
+
+/* ---- mixing: mixing/mixing.py -------------------------------------------------------- */
+typedef struct {
+  int32_t nx, ny;                 /* int(100 L), int(100 H) */
+  int32_t ndt_act, n_act;         /* 250, 100 */
+  int32_t nx_obs_pts, ny_obs_pts, nx_obs, ny_obs, n_obs_steps;
+  int32_t itmax;                  /* 300000 (mixing.py:426) */
+  int32_t i_min, i_max, j_min, j_max; /* initial patch, ARRAY indices (mixing.py:90-94) */
+  double dx, dy, dt;
+  double re, pe, u_max, C0, ref_c; /* ref_c = side^2/(L H) C0 (mixing.py:261) */
+  double tol;                     /* 1e-4 (mixing.py:423) */
+} bcn_mixing_cfg;
+
+/* replaces mixing.__init__ (mixing.py:20-70) */
+BCN_API int bcn_mixing_create(const bcn_mixing_cfg* cfg, int batch, int dtype, int device, bcn_env_t* out);
+/* replaces mixing.reset / reset_fields (mixing.py:73-111) */
+BCN_API int bcn_mixing_reset(bcn_env_t h, void* obs_dev, void* stream);
+/* replaces mixing.step (mixing.py:114-135) incl. solve/get_control/get_obs/get_rwd (:138-264).
+ * actions_dev int32[B] in {0,1,2,3} (anything else = walls at rest), NULL = repeat last. */
+BCN_API int bcn_mixing_step(bcn_env_t h, const int32_t* actions_dev, void* obs_dev, void* rwd_dev,
+                    uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev, int32_t* sweeps_dev,
+                    void* stream);
+
+/* ---- burgers: burgers/burgers.py ----------------------------------------------------- */
+typedef struct {
+  int32_t nx;                     /* 500 in the reference (burgers.py:26) */
+  int32_t ndt_act, n_act;         /* 62, 200 */
+  int32_t ctrl_pos, n_obs_pts;    /* 250, 5 */
+  double dx, dt, amp, u_target;
+} bcn_burgers_cfg;
+
+/* replaces burgers.__init__ (burgers.py:21-65) */
+BCN_API int bcn_burgers_create(const bcn_burgers_cfg* cfg, int batch, int dtype, int device, bcn_env_t* out);
+/* replaces burgers.reset (burgers.py:68-94) */
+BCN_API int bcn_burgers_reset(bcn_env_t h, void* obs_dev, void* stream);
+/* replaces burgers.step (burgers.py:97-166).  actions_dev[B] (NULL = repeat last);
+ * noise_dev[B]: the uniform(-sigma,sigma) inlet draw of this step (burgers.py:127), explicit. */
+BCN_API int bcn_burgers_step(bcn_env_t h, const void* actions_dev, const void* noise_dev, void* obs_dev,
+                     void* rwd_dev, uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev,
+                     void* stream);
+
+/* ---- shkadov: shkadov/shkadov.py ----------------------------------------------------- */
+typedef struct {
+  int32_t nx;                     /* int(5 (L0 + jet_space (n_jets+2))) */
+  int32_t ndt_act, n_act;         /* 50, 400 */
+  int32_t n_jets, jet_pos, jet_hw, jet_space; /* lattice units (shkadov.py:64-68) */
+  int32_t l_obs, l_rwd, n_obs, obs_stride, n_interp; /* 50, 50, 10, 5, 20 */
+  double dx, dt, delta, jet_amp, eps;
+  double h_blow;                  /* 5 h_max = 25 (shkadov.py:176) */
+  double blowup_rwd;              /* -1 */
+} bcn_shkadov_cfg;
+
+/* replaces shkadov.__init__ (shkadov.py:20-110) */
+BCN_API int bcn_shkadov_create(const bcn_shkadov_cfg* cfg, int batch, int dtype, int device, bcn_env_t* out);
+/* replaces shkadov.reset without its rand_init loop (shkadov.py:113-146): init_fields_dev [2][nx]
+ * (h_init, q_init) shared by all replicas, NULL = flat film h=q=1 (reset_fields only). */
+BCN_API int bcn_shkadov_reset(bcn_env_t h, const void* init_fields_dev, void* obs_dev, void* stream);
+/* replaces shkadov.step (shkadov.py:161-264).  actions_dev[B][n_jets] (NULL = repeat last);
+ * noise_dev[B][ndt_act]: inlet draws, one per timestep (shkadov.py:204). */
+BCN_API int bcn_shkadov_step(bcn_env_t h, const void* actions_dev, const void* noise_dev, void* obs_dev,
+                     void* rwd_dev, uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev,
+                     void* stream);
+
+/* ---- sloshing: sloshing/sloshing.py -------------------------------------------------- */
+typedef struct {
+  int32_t nx;                     /* int(80 L) */
+  int32_t ndt_act, n_act, n_interp; /* 50, 200, 10 */
+  double dx, dt, g, amp, alpha;
+} bcn_sloshing_cfg;
+
+/* replaces sloshing.__init__ (sloshing.py:20-89) */
+BCN_API int bcn_sloshing_create(const bcn_sloshing_cfg* cfg, int batch, int dtype, int device, bcn_env_t* out);
+/* replaces sloshing.reset (sloshing.py:92-124): init_fields_dev [2][nx+2] (h_init, q_init) or NULL */
+BCN_API int bcn_sloshing_reset(bcn_env_t h, const void* init_fields_dev, void* obs_dev, void* stream);
+/* replaces sloshing.step (sloshing.py:141-244).  actions_dev[B] (NULL = repeat last) */
+BCN_API int bcn_sloshing_step(bcn_env_t h, const void* actions_dev, void* obs_dev, void* rwd_dev,
+                      uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev, void* stream);
+
+/* ---- common -------------------------------------------------------------------------- */
+BCN_API int bcn_env_kind(bcn_env_t h);
+BCN_API int bcn_batch(bcn_env_t h);
+BCN_API int bcn_dtype(bcn_env_t h);
+BCN_API int bcn_n_obs(bcn_env_t h);       /* observation length per replica */
+BCN_API int bcn_n_act(bcn_env_t h);       /* action length per replica */
+/* Solver state of all replicas, the equivalent of the env's field attributes (and of
+ * dump()/load(), rayleigh.py:344-362): elements per replica, then copy out / in.  Layout per
+ * replica: rayleigh/mixing [4][ny+2][nx+2] = u,v,p,S; burgers [3][nx] = u,up,upp;
+ * shkadov [4][nx] = h,q,rhsh,rhsq; sloshing [4][nx+2] = h,q,rhsh,rhsq.  `buf` may be a host or a
+ * device pointer (is_device); host copies synchronise the stream. */
+BCN_API size_t bcn_state_elems(bcn_env_t h);
+BCN_API int bcn_get_state(bcn_env_t h, void* buf, int is_device, void* stream);
+BCN_API int bcn_set_state(bcn_env_t h, const void* buf, int is_device, void* stream);
+/* episode counter `stp` of every replica (rayleigh.py:126,155): int32[B] */
+BCN_API int bcn_get_stp(bcn_env_t h, int32_t* buf_host, void* stream);
+BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);
+/* Which kernel variant *_step uses: 0 = generic (any grid, fields in HBM/L2, Jacobi in LDS),
+ * 1 = register-resident CDNA4 path where the grid has one (falls back to 0 otherwise).
+ * Returns the variant actually selected. */
+BCN_API int bcn_set_variant(bcn_env_t h, int variant);
+/* name of the kernel *_step launches (for profiles) */
+BCN_API const char* bcn_kernel_name(bcn_env_t h);
+BCN_API int bcn_destroy(bcn_env_t h);
+BCN_API const char* bcn_last_error(void);
+BCN_API const char* bcn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEACON_HIP_H */

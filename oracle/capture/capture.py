@@ -408,7 +408,26 @@ def job_lorenz():
     save("lorenz", **out)
 
 
+def job_init_data():
+    """The reference's shipped developed-flow initial states (init_field.dat, text '%.5e'),
+    parsed exactly as each env's load() does (rayleigh.py:356-362, shkadov.py:364-368,
+    sloshing.py:309-313) and stored as float64 arrays: a DATA dependency of reset()."""
+    f = np.loadtxt(os.path.join(REF, "beacon", "rayleigh", "init_field.dat"))
+    n = f.shape[0] // 4
+    ray = np.stack([f[k * n:(k + 1) * n, :] for k in range(4)])
+    f = np.loadtxt(os.path.join(REF, "beacon", "shkadov", "init_field.dat"))
+    shk = np.stack([f[:, 1], f[:, 2]])
+    f = np.loadtxt(os.path.join(REF, "beacon", "sloshing", "init_field.dat"))
+    slo = np.zeros((2, f.shape[0] + 2))
+    slo[0, 1:-1], slo[1, 1:-1] = f[:, 1], f[:, 2]
+    path = os.path.join(REPO, "beacon_amd", "data", "init_fields.npz")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, rayleigh=ray, shkadov=shk, sloshing=slo)
+    print("wrote", path, ray.shape, shk.shape, slo.shape)
+
+
 JOBS = {
+    "init_data": job_init_data,
     "rayleigh_default": job_rayleigh_default,
     "rayleigh_128x64": job_rayleigh_128x64,
     "mixing_a0": lambda: job_mixing(0),

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (run with -m gpu on an MI355X box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def gold():
+    return golden
+
+
+def ref_to_dev(a):
+    """reference [.., nx+2, ny+2] -> device layout [.., ny+2, nx+2]"""
+    return np.ascontiguousarray(np.swapaxes(a, -1, -2))

@@ -1,0 +1,260 @@
+"""The CPU oracle (oracle/) against golden vectors captured from the unmodified reference
+(oracle/capture/capture.py).  float64, same operation order: fields/obs must match to the
+last bit or two; reductions (np.dot / np.sum / norm) may differ in the last bits only."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import oracle as O
+
+BIT = 0.0            # bit-exact
+RED = 5e-15          # relative slack for quantities that pass through a numpy/BLAS reduction
+
+
+def test_lorenz_episodes():
+    g = golden("lorenz")
+    for tag in ("a0", "a1", "a2", "rnd"):
+        e = O.lorenz()
+        o0, info = e.reset()
+        assert info is None and np.array_equal(o0, g[tag + "_reset_obs"])
+        obs, rwd, dn = [], [], []
+        for a in g[tag + "_actions"]:
+            o, r, d, t, _ = e.step(np.int64(a))
+            obs.append(o), rwd.append(r), dn.append([d, t])
+        assert np.array_equal(np.array(obs), g[tag + "_obs"])
+        assert np.array_equal(np.array(rwd), g[tag + "_rwd"])
+        assert np.array_equal(np.array(dn), g[tag + "_done"])
+
+
+def test_lorenz_fixed_point_known_answer():
+    # (0,0,0) is a fixed point of the unforced Lorenz system
+    e = O.lorenz()
+    e.reset()
+    e.x[:] = 0.0
+    o, r, _, _, _ = e.step(np.int64(1))
+    assert np.all(o == 0.0) and r == 0.0
+
+
+def test_burgers_episodes():
+    g = golden("burgers")
+    for s in (0, 1):
+        e = O.burgers()
+        o0, _ = e.reset()
+        assert np.array_equal(o0, g["s%d_reset_obs" % s])
+        obs, rwd, dn = [], [], []
+        for a, nz in zip(g["s%d_actions" % s], g["s%d_noise" % s]):
+            o, r, d, t, _ = e.step(a.tolist(), nz)
+            obs.append(o), rwd.append(r), dn.append([d, t])
+        assert np.array_equal(np.array(obs), g["s%d_obs" % s])
+        np.testing.assert_allclose(np.array(rwd), g["s%d_rwd" % s], rtol=RED, atol=1e-16)
+        assert np.array_equal(np.array(dn), g["s%d_done" % s])
+        for f in ("u", "up", "upp"):
+            assert np.array_equal(getattr(e, f), g["s%d_%s" % (s, f)])
+
+
+def test_burgers_constant_state_preserved():
+    # no noise, no action: u == u_target is a steady state
+    e = O.burgers()
+    e.reset()
+    for _ in range(3):
+        o, r, _, _, _ = e.step([0.0], 0.0)
+    assert np.all(e.u == 0.5) and r == 0.0
+
+
+@pytest.mark.parametrize("tag,kw,init", [("j5", dict(n_jets=5), True), ("j10", dict(n_jets=10), True),
+                                         ("n4096", dict(L0=699.2, n_jets=10), False)])
+def test_shkadov_episodes(tag, kw, init):
+    g = golden("shkadov")
+    e = O.shkadov(init=init, init_fields=np.stack([g[tag + "_h_init"], g[tag + "_q_init"]]), **kw)
+    e.rand_init = False
+    assert list(g[tag + "_params"][:2]) == [e.nx, e.cfg.ndt_act]
+    if init:
+        o0, _ = e.reset()
+    else:
+        e.reset_fields()
+        o0 = e.get_obs()
+    assert np.array_equal(o0, g[tag + "_reset_obs"])
+    obs, rwd = [], []
+    for a, nz in zip(g[tag + "_actions"], g[tag + "_noise"]):
+        o, r, d, t, _ = e.step(a.tolist(), nz)
+        obs.append(o), rwd.append(r)
+    assert np.array_equal(np.array(obs), g[tag + "_obs"])
+    np.testing.assert_allclose(np.array(rwd), g[tag + "_rwd"], rtol=RED, atol=1e-18)
+    for f in ("h", "q", "rhsh", "rhsq"):
+        assert np.array_equal(getattr(e, f), g[tag + "_" + f])
+
+
+def test_shkadov_rand_init_reset():
+    g = golden("shkadov")
+    e = O.shkadov(n_jets=5, init_fields=np.stack([g["j5_h_init"], g["j5_q_init"]]))
+    o0, _ = e.reset(int(g["rand_n"]), g["rand_noise"])
+    assert np.array_equal(o0, g["rand_reset_obs"])
+    assert np.array_equal(e.h, g["rand_h"]) and np.array_equal(e.q, g["rand_q"])
+    assert e.stp == 0
+
+
+def test_shkadov_flat_film_is_steady():
+    e = O.shkadov(init=False, n_jets=5)
+    e.reset_fields()
+    o, r, d, t, _ = e.step([0.0] * 5, np.zeros(50))
+    assert np.abs(e.h - 1.0).max() < 1e-8 and np.abs(e.q - 1.0).max() < 1e-8 and not d  # eps=1e-8 in q/(h^2+eps)
+
+
+def test_shkadov_blowup_flag():
+    e = O.shkadov(init=False, n_jets=5)
+    e.reset_fields()
+    e.h[:] = 1.0 + 30.0 * np.exp(-((np.arange(e.nx) - 400) / 20.0) ** 2)
+    o, r, d, t, _ = e.step([0.0] * 5, np.zeros(50))
+    assert d and not t and r == -1.0          # shkadov.py:176-180
+
+
+def test_sloshing_episode_and_warmup():
+    g = golden("sloshing")
+    e = O.sloshing(init_fields=np.stack([g["h_init"], g["q_init"]]))
+    o0, _ = e.reset()
+    assert np.array_equal(o0, g["reset_obs"])
+    obs, rwd = [], []
+    for a in g["actions"]:
+        o, r, d, t, _ = e.step(a.tolist())
+        obs.append(o), rwd.append(r)
+    assert np.array_equal(np.array(obs), g["obs"])
+    np.testing.assert_allclose(np.array(rwd), g["rwd"], rtol=RED)
+    for f in ("h", "q", "rhsh", "rhsq"):
+        assert np.array_equal(getattr(e, f), g[f])
+    e = O.sloshing(init=False)
+    e.reset_fields()
+    t = 0.0
+    for _ in range(e.n_warmup):
+        e.step([e.signal(t, e.dt_act)])
+        t += e.dt_act
+    assert np.array_equal(e.h, g["warm_h"]) and np.array_equal(e.q, g["warm_q"])
+
+
+def test_sloshing_rest_state_is_steady():
+    e = O.sloshing(init=False)
+    e.reset_fields()
+    o, r, d, t, _ = e.step([0.0])
+    assert np.all(e.h == 1.0) and np.all(e.q == 0.0) and r == 0.0
+
+
+def _ray_default():
+    g = golden("rayleigh_default")
+    e = O.rayleigh(init_fields=np.stack([g["u_init"], g["v_init"], g["p_init"], g["T_init"]]))
+    return g, e
+
+
+def test_rayleigh_default_three_steps():
+    g, e = _ray_default()
+    o0, info = e.reset()
+    assert info is None and np.array_equal(o0, g["reset_obs"])
+    assert np.count_nonzero(o0[:144]) == 0        # 3 empty history slots
+    for k in range(3):
+        a = g["actions"][k].tolist() if k < 2 else None
+        o, r, d, t, _ = e.step(a)
+        assert np.array_equal(e.itp, g["itp"][k])
+        assert np.array_equal(o, g["step%d_obs" % k])
+        assert r == pytest.approx(float(g["step%d_rwd" % k]), rel=RED)
+        for f, F in (("u", "u"), ("v", "v"), ("p", "p"), ("S", "T")):
+            assert np.array_equal(getattr(e, f), g["step%d_%s" % (k, F)])
+        assert np.array_equal(np.array(e.a), g["step%d_a_norm" % k])
+        if k < 2:
+            assert np.array_equal(np.array(a), g["step%d_a_mutated" % k])   # list normalised in place
+        assert [d, t] == list(g["step%d_done" % k])
+
+
+def test_rayleigh_stage_snapshots():
+    """Each kernel alone on the reference's own stage inputs (first 3 timesteps)."""
+    import ctypes as C
+    g, e = _ray_default()
+    L, cfg, dp = O.lib(), e.cfg, O.dp
+    n = (cfg.nx + 2) * (cfg.ny + 2)
+    for k in range(3):
+        u, v, p, T = (np.ascontiguousarray(g[x][k]) for x in ("bc_u", "bc_v", "bc_p", "bc_T"))
+        us, vs = np.zeros_like(u), np.zeros_like(u)
+        L.orc_ns2d_predictor(C.byref(cfg), dp(u), dp(v), dp(us), dp(vs), dp(p), dp(T))
+        # the reference never writes us[1,:], us[nx+1,:], vs[:,1], vs[:,ny+1]
+        assert np.array_equal(us, g["pred_us"][k]) and np.array_equal(vs, g["pred_vs"][k])
+        phi, phin, ovf = np.zeros(n), np.zeros(n), C.c_int(0)
+        itp = L.orc_ns2d_poisson(C.byref(cfg), dp(us), dp(vs), dp(phi), dp(phin), C.byref(ovf))
+        assert itp == g["itp"][0][k] and not ovf.value
+        assert np.array_equal(phi.reshape(u.shape), g["pois_phi"][k])
+        u2, v2 = u.copy(), v.copy()
+        L.orc_ns2d_corrector(C.byref(cfg), dp(u2), dp(v2), dp(us), dp(vs), dp(phi))
+        assert np.array_equal(u2, g["corr_u"][k]) and np.array_equal(v2, g["corr_v"][k])
+        T2 = np.ascontiguousarray(g["tran_in"][k]).copy()
+        L.orc_ns2d_transport(C.byref(cfg), dp(u2), dp(v2), dp(T2))
+        assert np.array_equal(T2, g["tran_out"][k])
+        # divergence-free after the corrector, to the Poisson tolerance
+        div = (u2[2:, 1:-1] - u2[1:-1, 1:-1]) / cfg.dx + (v2[1:-1, 2:] - v2[1:-1, 1:-1]) / cfg.dy
+        assert np.abs(div).max() < 5e-2
+
+
+def test_rayleigh_128x64_synthetic():
+    g = golden("rayleigh_128x64")
+    e = O.rayleigh(init=False, L=2.56, H=1.28)
+    assert (e.nx, e.ny, e.cfg.nx_sgts, e.n_obs_tot) == (128, 64, 12, 384)
+    e.reset_fields()
+    e.st[0], e.st[1], e.st[2], e.st[3] = g["u0"], g["v0"], g["p0"], g["T0"]
+    e.cfg.ndt_act = 5
+    assert np.array_equal(e.get_obs(), g["obs0"])
+    a = g["actions"][0].tolist()
+    o, r, d, t, _ = e.step(a)
+    assert np.array_equal(e.itp, g["itp"][0])
+    assert np.array_equal(o, g["step0_obs"])
+    for f, F in (("u", "u"), ("v", "v"), ("p", "p"), ("S", "T")):
+        assert np.array_equal(getattr(e, f), g["step0_" + F])
+    # bottom ghosts beyond the 10 x 12 segment cells are never touched (rayleigh.py:199-202)
+    assert np.array_equal(e.S[121:129, 0], g["T0"][121:129, 0])
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_mixing_from_rest(act):
+    g = golden("mixing_a%d" % act)
+    e = O.mixing()
+    o0, _ = e.reset()
+    assert np.array_equal(o0, g["reset_obs"]) and np.array_equal(e.S, g["reset_C"])
+    assert e.get_rwd() == pytest.approx(float(g["reset_rwd"]), rel=RED)
+    e.cfg.ndt_act = 3
+    o, r, d, t, _ = e.step(np.int64(act))
+    assert np.array_equal(e.itp, g["itp"][0])          # first solve from rest: 2466 sweeps
+    assert np.array_equal(o, g["step0_obs"])
+    assert r == pytest.approx(float(g["step0_rwd"]), rel=RED)
+    for f, F in (("u", "u"), ("v", "v"), ("p", "p"), ("S", "C")):
+        assert np.array_equal(getattr(e, f), g["step0_" + F])
+
+
+def test_mixing_synthetic_all_actions():
+    g = golden("mixing_synth")
+    for act in range(5):
+        e = O.mixing()
+        e.reset()
+        e.st[0], e.st[1], e.st[2] = g["u0"], g["v0"], g["p0"]
+        e.cfg.ndt_act = 4
+        o, r, d, t, _ = e.step(np.int64(act))
+        assert np.array_equal(e.itp, g["a%d_itp" % act])
+        assert np.array_equal(o, g["a%d_obs" % act])
+        for f, F in (("u", "u"), ("v", "v"), ("p", "p"), ("S", "C")):
+            assert np.array_equal(getattr(e, f), g["a%d_%s" % (act, F)])
+
+
+def test_poisson_manufactured_known_answer():
+    """Jacobi on a zero right-hand side converges in one sweep with phi == 0; a divergent
+    starred field gives a phi whose discrete Laplacian matches the rhs in the interior."""
+    import ctypes as C
+    e = O.rayleigh(init=False)
+    cfg, L, dp = e.cfg, O.lib(), O.dp
+    n = (cfg.nx + 2) * (cfg.ny + 2)
+    us, vs = np.zeros((52, 52)), np.zeros((52, 52))
+    phi, phin, ovf = np.zeros(n), np.zeros(n), C.c_int(0)
+    assert L.orc_ns2d_poisson(C.byref(cfg), dp(us), dp(vs), dp(phi), dp(phin), C.byref(ovf)) == 1
+    assert np.all(phi == 0.0)
+    cfg.tol = 1e-22
+    x = (np.arange(52) - 1.0) * cfg.dx
+    us[:, :] = 1e-3 * np.sin(2 * np.pi * x)[:, None]      # zero at both walls, zero-mean divergence
+    it = L.orc_ns2d_poisson(C.byref(cfg), dp(us), dp(vs), dp(phi), dp(phin), C.byref(ovf))
+    assert 1 < it < cfg.itmax and not ovf.value
+    ph = phi.reshape(52, 52)
+    lap = ((ph[2:, 1:-1] - 2 * ph[1:-1, 1:-1] + ph[:-2, 1:-1]) / cfg.dx ** 2 +
+           (ph[1:-1, 2:] - 2 * ph[1:-1, 1:-1] + ph[1:-1, :-2]) / cfg.dy ** 2)
+    b = ((us[2:, 1:-1] - us[1:-1, 1:-1]) / cfg.dx) / cfg.dt
+    assert np.abs(lap - b).max() < 1e-5 * np.abs(b).max()
