@@ -34,7 +34,7 @@ struct NS2DEnv : bcn_env_s {
   NS2DArgs<real> a{};
   DevBuf fields;    // u,v,p,S,us,vs   [6][B][ncell]
   DevBuf work;      // g0,g1,g2        [3][B][ncell]  (only when the work arrays do not fit LDS)
-  DevBuf obs_hist, a_last, ia_last, stpbuf;
+  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf;
   bool fast_ok = false;
 
   int init() {
@@ -63,6 +63,11 @@ struct NS2DEnv : bcn_env_s {
     if ((rc = stpbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
     BCN_HIP(hipMemset(stpbuf.p, 0, stpbuf.bytes));
     stp = a.stp = static_cast<int32_t*>(stpbuf.p);
+    if ((rc = sweepbuf.alloc((size_t)batch * (a.ndt_act > 0 ? a.ndt_act : 1) * sizeof(int32_t)))) return rc;
+    BCN_HIP(hipMemset(sweepbuf.p, 0, sweepbuf.bytes));
+    a.sweeps_int = static_cast<int32_t*>(sweepbuf.p);
+    if ((rc = orderbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
+    a.order_out = static_cast<int32_t*>(orderbuf.p);
     fast_ok = ns2d_fast_supported<real>(a);
     variant = fast_ok ? 1 : 0;
     return BCN_OK;
@@ -70,7 +75,7 @@ struct NS2DEnv : bcn_env_s {
   ~NS2DEnv() override {
     DeviceGuard g(device);
     fields.release(); work.release(); obs_hist.release(); a_last.release(); ia_last.release();
-    stpbuf.release();
+    stpbuf.release(); sweepbuf.release(); orderbuf.release();
   }
   size_t state_elems() const override { return 4 * (size_t)a.ncell; }
   // state buffer layout: [B][4][ncell]; device layout: [4][B][ncell]

@@ -40,6 +40,12 @@ struct NS2DArgs {
   int32_t* sweeps;
   const real* init_fields;  // reset only
   int work_in_lds;
+  // fast path only: timestep range of this launch and replica order (LPT scheduling, see ns2d_fast.hip)
+  int it_begin, it_end;
+  int first_chunk, last_chunk;
+  const int32_t* order;     // blockIdx -> replica, or NULL for identity
+  int32_t* order_out;       // rank kernel output
+  int32_t* sweeps_int;      // handle-owned [B][ndt_act] when the caller passes no sweeps buffer
 };
 
 // launchers (one per translation unit)

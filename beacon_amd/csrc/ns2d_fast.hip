@@ -1,12 +1,538 @@
-// ns2d_fast.hip -- register-resident CDNA4 rayleigh / mixing action step (variant 1).
-// Placeholder until the fast path lands: reports "no fast path for this grid".
-#include "ns2d.h"
+// ns2d_fast.hip -- register-resident CDNA4 rayleigh action step (variant 1).
+//
+// One workgroup of NW = NX/R waves per replica runs the whole action step on chip:
+//   * lanes run along y (lane l <-> row j = l+1, NY <= 64), wave w owns the R columns
+//     i = w*R+1 .. w*R+R, so every thread holds R consecutive x-cells of row j in VGPRs;
+//   * p, u*, v*, the Poisson rhs and phi live in registers for the whole step; u, v, T live
+//     in LDS in [i][j] order (lanes consecutive in j: bank-conflict free, also for the
+//     skewed accesses of the transport sweep); HBM is read once on entry, written once on exit;
+//   * Jacobi sweep: x-neighbours are the thread's own registers, y-neighbours come from the
+//     adjacent lanes by DPP wave shifts (whose boundary lanes give the Neumann ghost for
+//     free), only the two strip-edge columns of each wave go through a double-buffered LDS
+//     exchange -- ONE barrier per sweep, which also carries the convergence test: per-wave
+//     DPP-reduced partial sums of the squared increment, combined in a fixed order by every
+//     wave (deterministic sweep counts);
+//   * transport (the reference's in-place sweep, rayleigh.py:468-487): explicit part of all
+//     cells in parallel, then ONE wave walks the nx+ny-1 anti-diagonals with the two
+//     dependent FMAs per cell in registers (west = own previous value, south = DPP from the
+//     lane below), coefficients prefetched from LDS PD diagonals ahead.
+//
+// Semantics are those of ns2d_generic.hip (same citations); tests compare both variants.
+#include <stdlib.h>
 
-template <typename real> bool ns2d_fast_supported(const NS2DArgs<real>&) { return false; }
-template <typename real> int ns2d_launch_fast(const NS2DArgs<real>&, int, hipStream_t) {
+#include <type_traits>
+
+#include "ns2d.h"
+#include "ns2d_device.h"
+
+namespace {
+
+// ---- DPP primitives (verified on gfx950 by scripts/dpp_test.hip) ----------------------------
+template <int CTRL, int RM, int BM, bool BC>
+__device__ __forceinline__ float dpp(float oldv, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv),
+                                                               __builtin_bit_cast(int, v), CTRL, RM, BM, BC));
+}
+template <int CTRL, int RM, int BM, bool BC>
+__device__ __forceinline__ double dpp(double oldv, double v) {
+  const long long o = __builtin_bit_cast(long long, oldv), s = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)s, CTRL, RM, BM, BC);
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), CTRL, RM, BM, BC);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// value of the lane below (row j-1); lane 0 keeps `oldv`
+template <typename real> __device__ __forceinline__ real from_below(real oldv, real v) { return dpp<0x138, 0xf, 0xf, false>(oldv, v); }
+// value of the lane above (row j+1); lane 63 keeps `oldv`
+template <typename real> __device__ __forceinline__ real from_above(real oldv, real v) { return dpp<0x130, 0xf, 0xf, false>(oldv, v); }
+
+template <typename real>
+__device__ __forceinline__ real row16_sum(real s) {  // lane 15 of each 16-lane row: sum of the row
+  s += dpp<0x111, 0xf, 0xf, true>(real(0), s);
+  s += dpp<0x112, 0xf, 0xf, true>(real(0), s);
+  s += dpp<0x114, 0xf, 0xf, true>(real(0), s);
+  s += dpp<0x118, 0xf, 0xf, true>(real(0), s);
+  return s;
+}
+template <typename real>
+__device__ __forceinline__ real wave_sum_lane63(real s) {  // lane 63: sum over the wave
+  s = row16_sum(s);
+  s += dpp<0x142, 0xa, 0xf, false>(real(0), s);
+  s += dpp<0x143, 0xc, 0xf, false>(real(0), s);
+  return s;
+}
+__device__ __forceinline__ float read_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double read_lane(double v, int l) {
+  const long long s = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)s, l), hi = __builtin_amdgcn_readlane((int)(s >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int NX, int NY, int R>
+struct FastGeom {
+  static_assert(NX % R == 0, "strip width must divide nx");
+  static_assert(NY <= 64, "lanes run along y");
+  static constexpr int NW = NX / R;
+  static_assert(NW <= 16, "at most 16 waves");
+  static constexpr int NT = NW * 64;
+  static constexpr int SY = NY + 2;
+  static constexpr int SX = NX + 2;
+  static constexpr int SZ = SX * SY + 16;  // +16: lanes >= NY read (never write) past the array
+  static constexpr int PD = 4;             // transport prefetch depth (diagonals)
+  static constexpr size_t lds_elems() { return 3 * (size_t)SZ + 2 * NW * 2 * 64 + 32 + 64 + 32; }
+};
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
+  using G = FastGeom<NX, NY, R>;
+  constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  real* Ul = reinterpret_cast<real*>(smem);
+  real* Vl = Ul + SZ;
+  real* Tl = Vl + SZ;
+  real* exch = Tl + SZ;            // [2][NW][2][64]
+  real* errp = exch + 2 * NW * 2 * 64;  // [2][16]
+  real* sact = errp + 32;          // [64]
+  real* red = sact + 64;           // [32]
+
+  const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane + 1;
+  const bool active = lane < NY;
+  const int i0 = w * R + 1;
+  const size_t off = (size_t)b * A.ncell;
+  real* __restrict__ gu = A.u + off;
+  real* __restrict__ gv = A.v + off;
+  real* __restrict__ gp = A.p + off;
+  real* __restrict__ gS = A.S + off;
+  auto ex = [&](int buf, int wave, int which) -> real* { return exch + ((buf * NW + wave) * 2 + which) * 64; };
+
+  // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
+  for (int c = tid; c < SX * SY; c += NT) {
+    const int jj = c / SX, ii = c - jj * SX;
+    Ul[ii * SY + jj] = gu[c];
+    Vl[ii * SY + jj] = gv[c];
+    Tl[ii * SY + jj] = gS[c];
+  }
+  for (int c = SX * SY + tid; c < SZ; c += NT) { Ul[c] = 0; Vl[c] = 0; Tl[c] = 0; }
+  if (tid < 32) errp[tid] = 0;
+  real p[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) p[k] = active ? gp[j * SX + i0 + k] : real(0);
+
+  // ---- action conditioning (rayleigh.py:162-171); later chunks reuse the conditioned vector ----
+  if (!A.first_chunk) {
+    if (tid < A.n_sgts) sact[tid] = A.a_last[(size_t)b * A.n_sgts + tid];
+  } else {
+    const int n = A.n_sgts;
+    const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
+    real mean = 0;
+    for (int k = 0; k < n; k++) mean += src[k];
+    mean /= (real)n;
+    real m = 1;
+    for (int k = 0; k < n; k++) {
+      real t = bcn_abs(src[k] - mean) / A.C;
+      m = t > m ? t : m;
+    }
+    real mine = (tid < n) ? (src[tid] - mean) / m : real(0);
+    __syncthreads();
+    if (tid < n) {
+      sact[tid] = mine;
+      A.a_last[(size_t)b * n + tid] = mine;
+      if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
+    }
+  }
+  __syncthreads();
+
+  const real dt = A.dt, rdx = A.rdx, rdy = A.rdy, rdx2 = A.rdx2, rdy2 = A.rdy2;
+  const real cx = A.cx, cy = A.cy;
+  // err weight of this lane's row: ghosts copy their interior neighbour (rayleigh.py:432-449)
+  const real wl = active ? real(1) + (j == 1 ? 1 : 0) + ((j == NY && KIND == 0) ? 1 : 0) : real(0);
+  const real fW = (active && w == 0) ? real(1) : real(0);
+  const real fE = (active && w == NW - 1) ? real(1) : real(0);
+  // coefficient of the lane's own value from the y-ghosts (bottom: always Neumann; top: rayleigh)
+  const real cBy = cy * (real)((lane == 0 ? 1 : 0) + ((lane == NY - 1 && KIND == 0) ? 1 : 0));
+  const real actf = active ? real(1) : real(0);
+
+  int status = 0;
+  int xb = 0;
+#ifdef BCN_STAMP
+
+  const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (!A.first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
+  for (int it = A.it_begin; it < A.it_end && status == 0; it++) {
+    // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
+    for (int jj = 1 + tid; jj <= NY; jj += NT) {
+      Ul[1 * SY + jj] = 0;
+      Ul[(NX + 1) * SY + jj] = 0;
+      if (jj >= 2) {
+        Vl[0 * SY + jj] = -Vl[1 * SY + jj];
+        Vl[(NX + 1) * SY + jj] = -Vl[NX * SY + jj];
+      }
+      Tl[0 * SY + jj] = Tl[1 * SY + jj];
+      Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
+    }
+    for (int ii = 1 + tid; ii <= NX + 1; ii += NT) {
+      const bool wall = (ii == 1) || (ii == NX + 1);
+      const real utop = wall ? real(0) : Ul[ii * SY + NY];
+      const real ubot = wall ? real(0) : Ul[ii * SY + 1];
+      Ul[ii * SY + NY + 1] = -utop;
+      Ul[ii * SY + 0] = -ubot;
+      if (ii <= NX) {
+        Vl[ii * SY + NY + 1] = 0;
+        Vl[ii * SY + 1] = 0;
+        Tl[ii * SY + NY + 1] = 2 * A.Tc - Tl[ii * SY + NY];
+        const int k = (ii - 1) / A.nx_sgts;
+        if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
+      }
+    }
+    ex(xb, w, 1)[lane] = p[R - 1];
+    __syncthreads();
+
+    // ---- predictor (rayleigh.py:370-407) -> u*, v* in registers -----------------------------
+    real us[R], vs[R];
+    {
+      const real pWh = (w > 0) ? ex(xb, w - 1, 1)[lane] : real(0);
+      xb ^= 1;
+      real ur[R + 2], uS[R + 1], uN[R], vr[R + 2], vN[R + 1], vS[R], Tc[R];
+#pragma unroll
+      for (int k = 0; k < R + 2; k++) { ur[k] = Ul[(i0 - 1 + k) * SY + j]; vr[k] = Vl[(i0 - 1 + k) * SY + j]; }
+#pragma unroll
+      for (int k = 0; k < R + 1; k++) { uS[k] = Ul[(i0 + k) * SY + j - 1]; vN[k] = Vl[(i0 - 1 + k) * SY + j + 1]; }
+#pragma unroll
+      for (int k = 0; k < R; k++) { uN[k] = Ul[(i0 + k) * SY + j + 1]; vS[k] = Vl[(i0 + k) * SY + j - 1]; Tc[k] = Tl[(i0 + k) * SY + j]; }
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const int i = i0 + k;
+        const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
+        const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
+        const real pc = p[k];
+        const real pW = (k > 0) ? p[k > 0 ? k - 1 : 0] : pWh;
+        const real pS = from_below(pc, pc);
+        {
+          real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+          real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
+          real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
+          real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
+          real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
+          real pres = (pc - pW) * rdx;
+          us[k] = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
+        }
+        {
+          real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+          real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
+          real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
+          real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
+          real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
+          real pres = (pc - pS) * rdy;
+          const real buoy = (KIND == 0) ? Tc[k] : real(0);
+          vs[k] = (j >= 2 && active) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+        }
+      }
+    }
+    ex(xb, w, 0)[lane] = us[0];
+    __syncthreads();
+
+    // ---- Poisson rhs (rayleigh.py:424-426) ---------------------------------------------------
+    real nb[R];   // minus the scaled rhs
+    {
+      const real usE = (w < NW - 1) ? ex(xb, w + 1, 0)[lane] : real(0);   // u*[nx+1,.] = 0
+      xb ^= 1;
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const real ue = (k < R - 1) ? us[k < R - 1 ? k + 1 : 0] : usE;
+        const real vn = from_above(real(0), vs[k]);                        // v*[., ny+1] = 0 (lanes >= NY hold 0)
+        nb[k] = active ? -A.cb * ((ue - us[k]) * rdx + (vn - vs[k]) * rdy) : real(0);
+      }
+    }
+
+    // ---- Jacobi sweeps (rayleigh.py:419-454): one barrier per sweep --------------------------
+    // phi ping-pongs between two register arrays (two sweeps per loop trip, no copies).  After
+    // the barrier the LDS reads (error partials, strip-edge halos) are issued first and the
+    // R-2 interior cells of the NEXT sweep are computed while they are in flight; only then is
+    // the convergence test of the finished sweep evaluated (if it passes, the partial next
+    // sweep is simply dropped) and the two edge cells are completed.
+    real phA[R], phB[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) phA[k] = 0;
+    real hW = 0, hE = 0;            // halos of the current source array
+    real eL = 0, hWr = 0, hEr = 0;  // LDS reads in flight
+    int itp = 0;
+    bool finalB = false;
+    const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
+    auto cell = [&](real c, real e, real wv, real nbk) -> real {
+      const real q = cBy * c + nbk;                       // Neumann ghosts in y copy the cell itself
+      real ph;
+      if (EQ) {
+        real sum = e + wv;
+        sum += dpp<0x130, 0xf, 0xf, true>(real(0), c);    // north (lane+1); 0 past the last lane
+        sum += dpp<0x138, 0xf, 0xf, true>(real(0), c);    // south (lane-1); 0 below lane 0
+        ph = cx * sum + q;
+      } else {
+        const real ns = dpp<0x130, 0xf, 0xf, true>(real(0), c) + dpp<0x138, 0xf, 0xf, true>(real(0), c);
+        ph = cx * (e + wv) + (cy * ns + q);
+      }
+      if (NY < 64) ph *= actf;                            // lanes past the top row stay 0
+      return ph;
+    };
+#ifdef BCN_STAMP
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+#define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                        \
+    {                                                                                        \
+      real acc = 0;                                                                          \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                    \
+        const real ph = cell(SRC[k], SRC[k + 1], SRC[k - 1], nb[k]);                         \
+        const real d = ph - SRC[k];                                                          \
+        acc += d * d;                                                                        \
+        DST[k] = ph;                                                                         \
+      }                                                                                      \
+      if (itp > 0) {                                                                         \
+        const real err = read_lane(row16_sum<real>(eL), 15);                                 \
+        hW = (w > 0) ? hWr : SRC[0];                                                         \
+        hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                \
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }             \
+        if (!(err > A.tol)) { finalB = SRC_IS_B; break; }                                    \
+      }                                                                                      \
+      const real p0 = cell(SRC[0], SRC[1], hW, nb[0]);                                       \
+      const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
+      const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
+      DST[0] = p0;                                                                           \
+      DST[R - 1] = pl;                                                                       \
+      acc += d0 * d0;                                                                        \
+      acc += dl * dl;                                                                        \
+      const real tot63 = wave_sum_lane63<real>(wl * acc + fW * (d0 * d0) + fE * (dl * dl));  \
+      ex(xb, w, 0)[lane] = p0;                                                               \
+      ex(xb, w, 1)[lane] = pl;                                                               \
+      if (lane == 63) errp[xb * 16 + w] = tot63;                                             \
+      __syncthreads();                                                                       \
+      itp++;                                                                                 \
+      eL = errp[xb * 16 + (lane & 15)];                                                      \
+      hWr = ex(xb, wm, 1)[lane];                                                             \
+      hEr = ex(xb, wp, 0)[lane];                                                             \
+      xb ^= 1;                                                                               \
+    }
+    for (;;) {
+      BCN_SWEEP(phA, phB, false)
+      BCN_SWEEP(phB, phA, true)
+    }
+#undef BCN_SWEEP
+    if (finalB) {
+#pragma unroll
+      for (int k = 0; k < R; k++) phA[k] = phB[k];
+    }
+#ifdef BCN_STAMP   // diagnostic build only: cycles per sweep in the high half of the sweep count
+    {
+      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+      const int cps = (int)((st1 - st0) / (unsigned long long)(itp > 0 ? itp : 1));
+      if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp | (cps << 16);
+    }
+#else
+    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
+#endif
+
+    // ---- p += phi (rayleigh.py:219), corrector (rayleigh.py:460-464) -> LDS u, v --------------
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const int i = i0 + k;
+      const real ph = phA[k];
+      const real pw = (k > 0) ? phA[k > 0 ? k - 1 : 0] : hW;
+      const real ps = from_below(ph, ph);
+      p[k] += ph;
+      if (active) {
+        if (i >= 2) Ul[i * SY + j] = us[k] - dt * (ph - pw) * rdx;
+        if (j >= 2) Vl[i * SY + j] = vs[k] - dt * (ph - ps) * rdy;
+      }
+    }
+    __syncthreads();
+
+    // ---- transport, explicit part of every cell (rayleigh.py:468-487) ------------------------
+    {
+      real Ac[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const int c = (i0 + k) * SY + j;
+        const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
+        const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
+        const real expl = A.ksc * ((TE - 2 * T0) * rdx2 + (TN - 2 * T0) * rdy2) -
+                          (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
+                          (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
+        Ac[k] = T0 + dt * expl;
+      }
+      __syncthreads();   // every read of the old T is done
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < R; k++) Tl[(i0 + k) * SY + j] = Ac[k];
+      }
+    }
+    __syncthreads();
+
+    // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
+    if (w == 0) {
+      const real c0x = dt * A.ksc * rdx2, c1x = real(0.5) * dt * rdx;
+      const real c0y = dt * A.ksc * rdy2, c1y = real(0.5) * dt * rdy;
+      constexpr int NSTEP = NX + NY - 1;
+      real ra[PD], ru[PD], rv[PD], rg[PD];
+      auto prefetch = [&](int t, real& a, real& uu, real& vv, real& gs) {
+        const int i = t - lane + 1;
+        const bool ok = active && i >= 1 && i <= NX;
+        const int c = ok ? i * SY + j : 0;
+        a = Tl[c]; uu = Ul[c]; vv = Vl[c];
+        const int ig = (t + 1 <= NX) ? t + 1 : NX;
+        gs = Tl[ig * SY + 0];                         // south ghost of lane 0's cell (i = t+1)
+      };
+#pragma unroll
+      for (int q = 0; q < PD; q++) prefetch(q, ra[q], ru[q], rv[q], rg[q]);
+      real tp = Tl[0 * SY + j];                        // west ghost
+      for (int t0 = 0; t0 < NSTEP; t0 += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; q++) {
+          const int t = t0 + q;
+          const int i = t - lane + 1;
+          const bool ok = active && i >= 1 && i <= NX && t < NSTEP;
+          const real s = from_below(rg[q], tp);
+          const real aw = c0x + c1x * ru[q], as = c0y + c1y * rv[q];
+          const real tn = ra[q] + aw * tp + as * s;
+          if (ok) { tp = tn; Tl[i * SY + j] = tn; }
+          prefetch(t + PD, ra[q], ru[q], rv[q], rg[q]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- store: LDS [i][j] -> HBM [j][i]; p and its ghosts -------------------------------------
+  for (int c = tid; c < SX * SY; c += NT) {
+    const int jj = c / SX, ii = c - jj * SX;
+    gu[c] = Ul[ii * SY + jj];
+    gv[c] = Vl[ii * SY + jj];
+    gS[c] = Tl[ii * SY + jj];
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const int i = i0 + k, c = j * SX + i;
+      // a p ghost receives the same increments as its interior neighbour (phi ghosts copy it)
+      const real dp = p[k] - gp[c];
+      if (i == 1) gp[c - 1] += dp;
+      if (i == NX) gp[c + 1] += dp;
+      if (j == 1) gp[c - SX] += dp;
+      if (j == NY && KIND == 0) gp[c + SX] += dp;
+      gp[c] = p[k];
+    }
+  }
+  __syncthreads();
+#ifdef BCN_STAMP   // diagnostic build only: shader clock in MHz (s_memrealtime ticks at 100 MHz)
+  {
+    const unsigned long long kt1 = __builtin_amdgcn_s_memtime(), kr1 = __builtin_amdgcn_s_memrealtime();
+    status = (int)((kt1 - kt0) * 100ull / (kr1 - kr0 + 1));
+
+  }
+#endif
+  if (A.last_chunk) {
+    ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
+  } else if (tid == 0 && A.status) {
+    A.status[b] = status;
+  }
+}
+
+// ---- LPT ordering between the two launches of one step ---------------------------------------
+// A replica's Jacobi work varies ~10x across a batch (20..240 sweeps per timestep) and each
+// replica is a serial chain on one CU, so with ~2 replicas per CU the step time is set by
+// which CU happens to pick up a long replica late.  The work of the first Q timesteps
+// predicts the rest (r ~ 0.8), so the step runs as [0,Q) in index order, then the remaining
+// timesteps with replicas dispatched longest-first.
+__global__ __launch_bounds__(1024) void ns2d_rank_by_work(const int32_t* sweeps, int ndt, int q, int batch,
+                                                          int32_t* order) {
+  __shared__ int key[2048];
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+    int s = 0;
+    for (int t = 0; t < q; t++) s += sweeps[(size_t)b * ndt + t];
+    key[b] = s;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < batch; b += blockDim.x) {
+    const int mine = key[b];
+    int rank = 0;
+    for (int o = 0; o < batch; o++) rank += (key[o] > mine || (key[o] == mine && o < b)) ? 1 : 0;
+    order[rank] = b;
+  }
+}
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  using G = FastGeom<NX, NY, R>;
+  const size_t lds = G::lds_elems() * sizeof(real);
+  auto k = ns2d_fast_step<real, NX, NY, R, KIND, EQ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  NS2DArgs<real> c = a;
+  if (!c.sweeps) c.sweeps = c.sweeps_int;
+  // split only when replicas outnumber the CUs (otherwise every replica starts at once and
+  // the order cannot matter); BCN_LPT_MIN_BATCH overrides the threshold (tests)
+  static int min_batch = -1;
+  if (min_batch < 0) {
+    const char* e = getenv("BCN_LPT_MIN_BATCH");
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    min_batch = e ? atoi(e) : ncu + 1;
+  }
+  constexpr int Q = 10;
+  const bool split = batch >= min_batch && batch <= 2048 && a.ndt_act >= 4 * Q;
+  c.first_chunk = 1; c.order = nullptr; c.it_begin = 0;
+  if (!split) {
+    c.it_end = a.ndt_act; c.last_chunk = 1;
+    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  } else {
+    c.it_end = Q; c.last_chunk = 0;
+    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+    hipLaunchKernelGGL(ns2d_rank_by_work, dim3(1), dim3(1024), 0, s, c.sweeps, a.ndt_act, Q, batch, c.order_out);
+    c.first_chunk = 0; c.last_chunk = 1; c.it_begin = Q; c.it_end = a.ndt_act; c.order = c.order_out;
+    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  }
+  BCN_HIP(hipGetLastError());
+  return BCN_OK;
+}
+
+template <typename real, int NX, int NY, int R, int KIND>
+int launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  // dx == dy (every reference configuration): one multiply per cell instead of two
+  if (a.cx == a.cy) return launch_fast_eq<real, NX, NY, R, KIND, true>(a, batch, s);
+  return launch_fast_eq<real, NX, NY, R, KIND, false>(a, batch, s);
+}
+
+template <typename real>
+int fast_config(const NS2DArgs<real>& a) {
+  if (a.kind != 0 || a.n_sgts > 64) return 0;
+  if (a.nx == 128 && a.ny == 64 && sizeof(real) == 4) return 1;
+  if (a.nx == 50 && a.ny == 50) return 2;
+  return 0;
+}
+
+}  // namespace
+
+template <typename real>
+bool ns2d_fast_supported(const NS2DArgs<real>& a) { return fast_config<real>(a) != 0; }
+
+template <typename real>
+int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  switch (fast_config<real>(a)) {
+    case 1:
+      if constexpr (std::is_same<real, float>::value) return launch_fast<float, 128, 64, 8, 0>(a, batch, s);
+      break;
+    case 2: return launch_fast<real, 50, 50, 5, 0>(a, batch, s);
+    default: break;
+  }
   bcn_set_error("no register-resident kernel for this grid");
   return BCN_ERR_UNSUPPORTED;
 }
+
 template bool ns2d_fast_supported<float>(const NS2DArgs<float>&);
 template bool ns2d_fast_supported<double>(const NS2DArgs<double>&);
 template int ns2d_launch_fast<float>(const NS2DArgs<float>&, int, hipStream_t);

@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--variant", type=int, default=-1, help="-1 = best available, 0 = generic kernel")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--zero-actions", action="store_true",
+                    help="diagnostic: uncontrolled steady flow (1 Jacobi sweep per timestep) -> non-Poisson cost")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +104,8 @@ def main():
         env.set_variant(args.variant)
     senv = ShardedVecEnv(env)
     acts_np = np.random.default_rng(1234 + rank).uniform(-1.0, 1.0, (W + K, B, env.n_sgts))
+    if args.zero_actions:
+        acts_np[:] = 0.0
     acts = torch.as_tensor(acts_np, dtype=env.tdtype, device=dev)
     senv.reset()
     sweeps_all = []
