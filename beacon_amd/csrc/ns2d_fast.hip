@@ -25,6 +25,10 @@
 #include "ns2d.h"
 #include "ns2d_device.h"
 
+#ifndef BCN_R128
+#define BCN_R128 8
+#endif
+
 namespace {
 
 // ---- DPP primitives (verified on gfx950 by scripts/dpp_test.hip) ----------------------------
@@ -44,6 +48,23 @@ __device__ __forceinline__ double dpp(double oldv, double v) {
 template <typename real> __device__ __forceinline__ real from_below(real oldv, real v) { return dpp<0x138, 0xf, 0xf, false>(oldv, v); }
 // value of the lane above (row j+1); lane 63 keeps `oldv`
 template <typename real> __device__ __forceinline__ real from_above(real oldv, real v) { return dpp<0x130, 0xf, 0xf, false>(oldv, v); }
+
+// acc + (value of the lane above / below, 0 outside the wave) as ONE v_add_f32_dpp.  hipcc fuses the
+// DPP move into the add only for some of the stencil cells; the asm form makes it unconditional.
+// Safe w.r.t. the VALU-write -> DPP-read hazard (2 wait states) as used here: the DPP source is a
+// phi register written a whole half-sweep earlier.
+__device__ __forceinline__ float add_above(float acc, float c) {
+  float r;
+  asm("v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ float add_below(float acc, float c) {
+  float r;
+  asm("v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ double add_above(double acc, double c) { return acc + dpp<0x130, 0xf, 0xf, true>(0.0, c); }
+__device__ __forceinline__ double add_below(double acc, double c) { return acc + dpp<0x138, 0xf, 0xf, true>(0.0, c); }
 
 template <typename real>
 __device__ __forceinline__ real row16_sum(real s) {  // lane 15 of each 16-lane row: sum of the row
@@ -80,21 +101,90 @@ struct FastGeom {
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY + 16;  // +16: lanes >= NY read (never write) past the array
   static constexpr int PD = 4;             // transport prefetch depth (diagonals)
-  static constexpr size_t lds_elems() { return 3 * (size_t)SZ + 2 * NW * 2 * 64 + 32 + 64 + 32; }
+  // LDS map (elements): [ exchange 2*NW*2*64 | errp 32 | sact 64 | red 32 | .. FRONT ) U V T [ BACK )
+  // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
+  // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
+  static constexpr int MISC = 2 * NW * 2 * 64 + 128;
+  static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
+  static constexpr int BACK = (NY + PD + 1) * SY;
+  static constexpr size_t lds_elems() { return (size_t)FRONT + 3 * (size_t)SZ + BACK; }
 };
+
+// Ordered part of the transport step, run by ONE wave (kept out of line: its unrolled,
+// software-pipelined loops would otherwise inflate the register pressure of the whole kernel).
+template <typename real, int NX, int NY, int R>
+__device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* Ul, const real* Vl, real* dummy,
+                                                          real c0x, real c1x, real c0y, real c1y) {
+  using G = FastGeom<NX, NY, R>;
+  constexpr int SY = G::SY, PD = G::PD;
+  const int lane = threadIdx.x & 63;
+  const int j = lane + 1;
+  const bool active = lane < NY;
+      constexpr int NSTEP = NX + NY - 1;
+      // At step t this lane works on cell (i, j) = (t - lane + 1, lane + 1), index cb + t*SY.  The
+      // element just below it, index - 1, is the south ghost T[i][0] for lane 0 (never written
+      // here, so it can be prefetched); the other lanes take their south value from the lane
+      // below by DPP and ignore it.  Reads are unmasked (see the LDS map), only writes are.
+      const int cb = (1 - lane) * SY + j;
+      real* Tb = Tl + cb;
+      const real* Ub = Ul + cb;
+      const real* Vb = Vl + cb;
+      real ra[PD], ru[PD], rv[PD], rg[PD];
+#pragma unroll
+      for (int q = 0; q < PD; q++) { ra[q] = Tb[q * SY]; ru[q] = Ub[q * SY]; rv[q] = Vb[q * SY]; rg[q] = Tb[q * SY - 1]; }
+      real tp = Tl[0 * SY + j];                        // west ghost
+      // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
+#define BCN_CHAIN(T0, T1, MASK)                                                             \
+      for (int t0 = (T0); t0 < (T1); t0 += PD) {                                            \
+        _Pragma("unroll") for (int q = 0; q < PD; q++) {                                    \
+          const int t = t0 + q;                                                             \
+          const real s = from_below(rg[q], tp);                                             \
+          const real aw = c0x + c1x * ru[q], as = c0y + c1y * rv[q];                        \
+          const real tn = ra[q] + aw * tp + as * s;                                         \
+          if (MASK == 0) {                                                                  \
+            tp = tn;                                                                        \
+            Tb[t * SY] = tn;                                                                \
+          } else {                                                                          \
+            const bool ok = active && (MASK != 2 ? (lane <= t) : true) &&                   \
+                            (MASK != 1 ? (lane > t - NX && t < NSTEP) : true);              \
+            tp = ok ? tn : tp;                                                              \
+            real* dst = ok ? Tb + t * SY : dummy;                                           \
+            *dst = tn;                                                                      \
+          }                                                                                 \
+          ra[q] = Tb[(t + PD) * SY];                                                        \
+          ru[q] = Ub[(t + PD) * SY];                                                        \
+          rv[q] = Vb[(t + PD) * SY];                                                        \
+          rg[q] = Tb[(t + PD) * SY - 1];                                                    \
+        }                                                                                   \
+      }
+      // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of PD
+      constexpr int TA = ((NY - 1 + PD - 1) / PD) * PD;      // first steady step (rounded up)
+      constexpr int TB = (NX / PD) * PD;                      // end of the steady phase (rounded down)
+      if constexpr (TA <= TB) {
+        BCN_CHAIN(0, TA, 1)
+        if (NY == 64) { BCN_CHAIN(TA, TB, 0) } else { BCN_CHAIN(TA, TB, 1) }
+        BCN_CHAIN(TB, NSTEP, 2)
+      } else {                                               // (nearly) square grid: no steady phase
+        constexpr int TL = ((NY - 1) / PD) * PD, TH = ((NX + PD - 1) / PD) * PD;
+        BCN_CHAIN(0, TL, 1)
+        BCN_CHAIN(TL, TH, 3)
+        BCN_CHAIN(TH, NSTEP, 2)
+      }
+#undef BCN_CHAIN
+    }
 
 template <typename real, int NX, int NY, int R, int KIND, bool EQ>
 __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
   using G = FastGeom<NX, NY, R>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  real* Ul = reinterpret_cast<real*>(smem);
+  real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
+  real* errp = exch + 2 * NW * 2 * 64;         // [2][16]
+  real* sact = errp + 32;                      // [64]
+  real* red = sact + 64;                       // [32]
+  real* Ul = exch + G::FRONT;
   real* Vl = Ul + SZ;
   real* Tl = Vl + SZ;
-  real* exch = Tl + SZ;            // [2][NW][2][64]
-  real* errp = exch + 2 * NW * 2 * 64;  // [2][16]
-  real* sact = errp + 32;          // [64]
-  real* red = sact + 64;           // [32]
 
   const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -158,8 +248,12 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
   int status = 0;
   int xb = 0;
 #ifdef BCN_STAMP
-
   const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tl = kt0;
+#define BCN_PH(x) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); seg[x] += t__ - tl; tl = t__; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BCN_PH(x)
 #endif
   if (!A.first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
   for (int it = A.it_begin; it < A.it_end && status == 0; it++) {
@@ -190,6 +284,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
     }
     ex(xb, w, 1)[lane] = p[R - 1];
     __syncthreads();
+    BCN_PH(0)
 
     // ---- predictor (rayleigh.py:370-407) -> u*, v* in registers -----------------------------
     real us[R], vs[R];
@@ -248,6 +343,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
       }
     }
 
+    BCN_PH(1)
     // ---- Jacobi sweeps (rayleigh.py:419-454): one barrier per sweep --------------------------
     // phi ping-pongs between two register arrays (two sweeps per loop trip, no copies).  After
     // the barrier the LDS reads (error partials, strip-edge halos) are issued first and the
@@ -267,8 +363,8 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
       real ph;
       if (EQ) {
         real sum = e + wv;
-        sum += dpp<0x130, 0xf, 0xf, true>(real(0), c);    // north (lane+1); 0 past the last lane
-        sum += dpp<0x138, 0xf, 0xf, true>(real(0), c);    // south (lane-1); 0 below lane 0
+        sum = add_above(sum, c);                          // north (lane+1); 0 past the last lane
+        sum = add_below(sum, c);                          // south (lane-1); 0 below lane 0
         ph = cx * sum + q;
       } else {
         const real ns = dpp<0x130, 0xf, 0xf, true>(real(0), c) + dpp<0x138, 0xf, 0xf, true>(real(0), c);
@@ -333,6 +429,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 #endif
 
+    BCN_PH(2)
     // ---- p += phi (rayleigh.py:219), corrector (rayleigh.py:460-464) -> LDS u, v --------------
 #pragma unroll
     for (int k = 0; k < R; k++) {
@@ -348,6 +445,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
     }
     __syncthreads();
 
+    BCN_PH(3)
     // ---- transport, explicit part of every cell (rayleigh.py:468-487) ------------------------
     {
       real Ac[R];
@@ -369,38 +467,14 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
     }
     __syncthreads();
 
+    BCN_PH(4)
     // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
     if (w == 0) {
-      const real c0x = dt * A.ksc * rdx2, c1x = real(0.5) * dt * rdx;
-      const real c0y = dt * A.ksc * rdy2, c1y = real(0.5) * dt * rdy;
-      constexpr int NSTEP = NX + NY - 1;
-      real ra[PD], ru[PD], rv[PD], rg[PD];
-      auto prefetch = [&](int t, real& a, real& uu, real& vv, real& gs) {
-        const int i = t - lane + 1;
-        const bool ok = active && i >= 1 && i <= NX;
-        const int c = ok ? i * SY + j : 0;
-        a = Tl[c]; uu = Ul[c]; vv = Vl[c];
-        const int ig = (t + 1 <= NX) ? t + 1 : NX;
-        gs = Tl[ig * SY + 0];                         // south ghost of lane 0's cell (i = t+1)
-      };
-#pragma unroll
-      for (int q = 0; q < PD; q++) prefetch(q, ra[q], ru[q], rv[q], rg[q]);
-      real tp = Tl[0 * SY + j];                        // west ghost
-      for (int t0 = 0; t0 < NSTEP; t0 += PD) {
-#pragma unroll
-        for (int q = 0; q < PD; q++) {
-          const int t = t0 + q;
-          const int i = t - lane + 1;
-          const bool ok = active && i >= 1 && i <= NX && t < NSTEP;
-          const real s = from_below(rg[q], tp);
-          const real aw = c0x + c1x * ru[q], as = c0y + c1y * rv[q];
-          const real tn = ra[q] + aw * tp + as * s;
-          if (ok) { tp = tn; Tl[i * SY + j] = tn; }
-          prefetch(t + PD, ra[q], ru[q], rv[q], rg[q]);
-        }
-      }
+      transport_chain<real, NX, NY, R>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+                                       dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     }
     __syncthreads();
+    BCN_PH(5)
   }
 
   // ---- store: LDS [i][j] -> HBM [j][i]; p and its ghosts -------------------------------------
@@ -428,6 +502,8 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
   {
     const unsigned long long kt1 = __builtin_amdgcn_s_memtime(), kr1 = __builtin_amdgcn_s_memrealtime();
     status = (int)((kt1 - kt0) * 100ull / (kr1 - kr0 + 1));
+    if (tid == 0 && A.actions_norm)
+      for (int q = 0; q < 6; q++) A.actions_norm[(size_t)b * A.n_sgts + q] = (real)seg[q] / (real)(A.it_end - A.it_begin);
 
   }
 #endif
@@ -524,7 +600,7 @@ template <typename real>
 int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   switch (fast_config<real>(a)) {
     case 1:
-      if constexpr (std::is_same<real, float>::value) return launch_fast<float, 128, 64, 8, 0>(a, batch, s);
+      if constexpr (std::is_same<real, float>::value) return launch_fast<float, 128, 64, BCN_R128, 0>(a, batch, s);
       break;
     case 2: return launch_fast<real, 50, 50, 5, 0>(a, batch, s);
     default: break;

@@ -27,6 +27,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def measured_traffic(kernel_name):
+    """HBM bytes per step() from the committed rocprofv3 PMC passes (scripts/prof_bench.sh ->
+    profiles/*_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, (2*FETCH + WRITE)*1024 as the
+    MI355X guide prescribes for gfx950), summed over the dispatches of one step.  None if absent."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for name, c in d.get("pmc", {}).items():
+            if name.startswith(kernel_name) and "hbm_bytes_per_dispatch" in c:
+                calls = d.get("kernels", {}).get(name, {}).get("calls")
+                n = c["FETCH_SIZE"]["dispatches"]
+                steps = d.get("bench_steps_incl_warmup", 6)
+                best = {"bytes_per_step": c["hbm_bytes_per_dispatch"] * n / steps, "source": os.path.basename(f)}
+    return best
+
+
 def algorithmic_bytes(nx, ny, sweeps, esz):
     """per interior cell 20 values per timestep + 3 values per Jacobi sweep."""
     cells = nx * ny
@@ -154,7 +174,9 @@ def main():
                        "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world,
                        "kernel": env.kernel_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (measured_traffic(env.kernel_name) or {}).get("bytes_per_step"),
+                         "traffic_source": (measured_traffic(env.kernel_name) or {}).get("source"),
                          "kernel": env.kernel_name, "avg_launch_ms": sum(kern_ms) / len(kern_ms),
                          "algorithmic_bytes_per_launch": sum(alg) / len(alg),
                          "note": "effective GB/s = SURVEY 8d algorithmic bytes / launch time; state stays "

@@ -1,0 +1,19 @@
+# diagnostic: build variants of the fast kernel (-D flags) and report cycles/sweep + step time
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from beacon_amd import build
+extra = sys.argv[1:]
+build.FLAGS.extend(["-DBCN_STAMP"] + extra); build.build_lib(force=True)
+from beacon_amd import vec as V
+z = np.load("tests/golden/rayleigh_128x64_init.npz")
+B = 512
+env = V.VecRayleigh(B, "cuda:0", "f32", z["fields"], L=2.56, H=1.28)
+env.reset()
+acts = np.random.default_rng(0).uniform(-1, 1, (3, B, 10))
+for k in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    env.step(acts[k]); torch.cuda.synchronize(); t1 = time.perf_counter()
+    sw = env.sweeps.cpu().numpy(); itp, cps = sw & 0xffff, sw >> 16
+print(extra, "step ms %.2f" % ((t1 - t0) * 1e3), "sweeps/dt %.1f" % itp.mean(), "cycles/sweep %.0f" % ((cps * itp).sum() / itp.sum()),
+      "clock MHz %.0f" % env.status.cpu().numpy().mean(),
+      "cycles/timestep BC/pred+rhs/jacobi/corr/transp-expl/chain", env.actions_norm.cpu().numpy()[:, :6].mean(0).round(0))
