@@ -9,6 +9,7 @@ Importing the package does not touch the GPU; constructing an env does, and rais
 library or a ROCm device is missing (there is no CPU fallback for the solver path)."""
 from .vec import Box, Discrete, VecBurgers, VecEnv, VecMixing, VecRayleigh, VecShkadov, VecSloshing  # noqa: F401
 from .lorenz import lorenz  # noqa: F401
+from .vortex import vortex  # noqa: F401
 
 __version__ = "0.1.0"
 

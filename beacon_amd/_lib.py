@@ -81,6 +81,7 @@ SIGNATURES = {
     "bcn_state_elems": (C.c_size_t, [vp]),
     "bcn_get_state": (C.c_int, [vp, vp, C.c_int, vp]),
     "bcn_set_state": (C.c_int, [vp, vp, C.c_int, vp]),
+    "bcn_set_mask": (C.c_int, [vp, vp]),
     "bcn_get_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_variant": (C.c_int, [vp, C.c_int]),

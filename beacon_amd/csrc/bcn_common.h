@@ -61,6 +61,7 @@ struct bcn_env_s {
   virtual int get_state(void* buf, int is_device, hipStream_t s) = 0;
   virtual int set_state(const void* buf, int is_device, hipStream_t s) = 0;
   virtual int set_variant(int v) { variant = 0; (void)v; return 0; }
+  virtual void set_mask(const uint8_t* m) = 0;
   virtual const char* kernel_name() const = 0;
   int32_t* stp = nullptr;  // device int32[B]
 };

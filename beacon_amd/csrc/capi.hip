@@ -97,6 +97,7 @@ struct NS2DEnv : bcn_env_s {
     return copy_state(const_cast<void*>(buf), is_device, s, false);
   }
   int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; return variant; }
+  void set_mask(const uint8_t* m) override { a.mask = m; }
   const char* kernel_name() const override { return variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step"; }
   int launch(hipStream_t s) {
     if (variant == 1) return ns2d_launch_fast<real>(a, batch, s);
@@ -212,6 +213,7 @@ struct Env1D : bcn_env_s {
     return copy_state(const_cast<void*>(buf), is_device, s, false);
   }
   const char* kernel_name() const override { return kname; }
+  void set_mask(const uint8_t* m) override { a.mask = m; }
 };
 
 template <typename real>
@@ -496,6 +498,11 @@ int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   BCN_HIP(hipMemcpyAsync(h->stp, buf_host, (size_t)h->batch * sizeof(int32_t), hipMemcpyHostToDevice, s));
   BCN_HIP(hipStreamSynchronize(s));
+  return BCN_OK;
+}
+int bcn_set_mask(bcn_env_t h, const uint8_t* mask_dev) {
+  if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }
+  h->set_mask(mask_dev);
   return BCN_OK;
 }
 int bcn_set_variant(bcn_env_t h, int variant) { return h ? h->set_variant(variant) : 0; }

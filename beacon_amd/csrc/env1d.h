@@ -28,6 +28,7 @@ struct Env1DArgs {
   const real* actions;
   const real* noise;
   const real* init_fields;
+  const uint8_t* mask;      // per-replica enable (NULL = all)
   real* obs_out;
   real* rwd_out;
   uint8_t* done;

@@ -52,6 +52,7 @@ __device__ real burgers_obs_rwd(const Env1DArgs<real>& A, int b, real* red) {
 
 template <typename real, int K, int NT>
 __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
+  if (A.mask && !A.mask[blockIdx.x]) return;
   constexpr int NB = (2 * NT * K * sizeof(real) <= 65536) ? 2 : 1;
   __shared__ real lds[NB][NT * K];
   __shared__ real red[NT / BCN_WAVE];
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
 
 template <typename real, int NT>
 __global__ __launch_bounds__(NT) void burgers_reset_k(Env1DArgs<real> A) {
+  if (A.mask && !A.mask[blockIdx.x]) return;
   __shared__ real red[NT / BCN_WAVE];
   const int b = blockIdx.x, n = A.n;
   for (int c = threadIdx.x; c < n; c += NT) {
@@ -168,6 +170,7 @@ __device__ real shkadov_obs_rwd(const Env1DArgs<real>& A, int b, real* red, bool
 
 template <typename real, int K, int NT>
 __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
+  if (A.mask && !A.mask[blockIdx.x]) return;
   constexpr int NB = (4 * NT * K * sizeof(real) <= 65536) ? 2 : 1;
   __shared__ real lh[NB][NT * K];
   __shared__ real lq[NB][NT * K];
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
 
 template <typename real, int NT>
 __global__ __launch_bounds__(NT) void shkadov_reset_k(Env1DArgs<real> A) {
+  if (A.mask && !A.mask[blockIdx.x]) return;
   __shared__ real red[NT / BCN_WAVE];
   const int b = blockIdx.x, n = A.n;
   for (int c = threadIdx.x; c < n; c += NT) {
@@ -336,6 +340,7 @@ __device__ real sloshing_obs_rwd(const Env1DArgs<real>& A, int b, real ua, real*
 
 template <typename real, int K, int NT>
 __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
+  if (A.mask && !A.mask[blockIdx.x]) return;
   constexpr int NB = (4 * NT * K * sizeof(real) <= 65536) ? 2 : 1;
   __shared__ real lh[NB][NT * K];
   __shared__ real lq[NB][NT * K];
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
 
 template <typename real, int NT>
 __global__ __launch_bounds__(NT) void sloshing_reset_k(Env1DArgs<real> A) {
+  if (A.mask && !A.mask[blockIdx.x]) return;
   __shared__ real red[NT / BCN_WAVE];
   const int b = blockIdx.x, n = A.n;
   for (int c = threadIdx.x; c < n; c += NT) {

@@ -39,6 +39,7 @@ struct NS2DArgs {
   int32_t* status;
   int32_t* sweeps;
   const real* init_fields;  // reset only
+  const uint8_t* mask;      // per-replica enable (NULL = all)
   int work_in_lds;
   // fast path only: timestep range of this launch and replica order (LPT scheduling, see ns2d_fast.hip)
   int it_begin, it_end;

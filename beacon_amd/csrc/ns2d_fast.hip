@@ -187,6 +187,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
   real* Tl = Vl + SZ;
 
   const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane + 1;
   const bool active = lane < NY;
@@ -521,11 +522,12 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
 // predicts the rest (r ~ 0.8), so the step runs as [0,Q) in index order, then the remaining
 // timesteps with replicas dispatched longest-first.
 __global__ __launch_bounds__(1024) void ns2d_rank_by_work(const int32_t* sweeps, int ndt, int q, int batch,
-                                                          int32_t* order) {
+                                                          int32_t* order, const uint8_t* mask) {
   __shared__ int key[2048];
   for (int b = threadIdx.x; b < batch; b += blockDim.x) {
     int s = 0;
-    for (int t = 0; t < q; t++) s += sweeps[(size_t)b * ndt + t];
+    if (!mask || mask[b])
+      for (int t = 0; t < q; t++) s += sweeps[(size_t)b * ndt + t];
     key[b] = s;
   }
   __syncthreads();
@@ -568,7 +570,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   } else {
     c.it_end = Q; c.last_chunk = 0;
     hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
-    hipLaunchKernelGGL(ns2d_rank_by_work, dim3(1), dim3(1024), 0, s, c.sweeps, a.ndt_act, Q, batch, c.order_out);
+    hipLaunchKernelGGL(ns2d_rank_by_work, dim3(1), dim3(1024), 0, s, c.sweeps, a.ndt_act, Q, batch, c.order_out, c.mask);
     c.first_chunk = 0; c.last_chunk = 1; c.it_begin = Q; c.it_end = a.ndt_act; c.order = c.order_out;
     hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   }

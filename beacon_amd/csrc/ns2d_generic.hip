@@ -27,6 +27,7 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NT / BCN_WAVE;
   const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
   const int tid = threadIdx.x;
   const int tx = tid & (BCN_WAVE - 1), ty = tid >> 6;
   const int nx = A.nx, ny = A.ny, sx = A.sx;
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
 template <typename real, int NT>
 __global__ __launch_bounds__(NT) void ns2d_reset_kernel(NS2DArgs<real> A) {
   const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
   const size_t off = (size_t)b * A.ncell;
   for (int c = threadIdx.x; c < A.ncell; c += NT) {
     real u0 = 0, v0 = 0, p0 = 0, s0 = 0;

@@ -105,6 +105,20 @@ class rayleigh(_Single):
         np.savetxt(field_name, np.vstack(_fields_2d(self.vec.get_state())), fmt="%.5e")
         np.savetxt(act_name, self.a, fmt="%.5e")
 
+    def load(self, filename):
+        """Read an init file in the reference's format (rayleigh.py:356-362) and make it the state
+        that reset() restores."""
+        f = np.loadtxt(filename)
+        n = self.nx + 2
+        fields = np.stack([f[k * n:(k + 1) * n, :] for k in range(4)])
+        v = self.vec
+        v._init_np = fields
+        v._init_dev = v._real(np.ascontiguousarray(fields.transpose(0, 2, 1)), (4, self.ny + 2, self.nx + 2))
+
+    def warmup(self):
+        """rayleigh.warmup (rayleigh.py:131-135): n_warmup uncontrolled action steps."""
+        self.vec.warmup(self.n_warmup)
+
 
 class mixing(_Single):
     """mixing/mixing.py:16-378"""
@@ -140,6 +154,12 @@ class mixing(_Single):
     v = property(lambda self: self._field(1))
     p = property(lambda self: self._field(2))
     C = property(lambda self: self._field(3))
+
+    def dump(self, field_name, action_name):
+        """Same formats as mixing.py:362-373 (4 stacked blocks u,v,p,C '%.5e'; action appended)."""
+        np.savetxt(field_name, np.vstack(_fields_2d(self.vec.get_state())), fmt="%.5e")
+        with open(action_name, "a") as f:
+            f.write(str(self.a) + "\n")
 
 
 class burgers(_Single):
@@ -228,6 +248,14 @@ class shkadov(_Single):
         np.savetxt(field_name, np.transpose(np.vstack((x, self.h, self.q))), fmt="%.5e")
         np.savetxt(jet_name, self.u, fmt="%.5e")
 
+    def load(self, filename):
+        """shkadov.py:364-368: first nx rows of columns 1 (h) and 2 (q)."""
+        f = np.loadtxt(filename)
+        v = self.vec
+        v._init_np = np.stack([f[:self.nx, 1], f[:self.nx, 2]])
+        v._init_dev = v._real(np.ascontiguousarray(v._init_np), (2, self.nx))
+        self.init = True
+
 
 class sloshing(_Single):
     """sloshing/sloshing.py:16-320"""
@@ -263,3 +291,88 @@ class sloshing(_Single):
 
     h = property(lambda self: self._np(self.vec.get_state())[0, 0])
     q = property(lambda self: self._np(self.vec.get_state())[0, 1])
+
+
+    def dump(self, field_name, control_name=None):
+        """Same text format as sloshing.py:297-307 (columns x, h[1:nx+1], q[1:nx+1])."""
+        x = np.linspace(0, self.nx, num=self.nx, endpoint=False) * self.dx
+        np.savetxt(field_name, np.transpose(np.vstack((x, self.h[1:self.nx + 1], self.q[1:self.nx + 1]))), fmt="%.5e")
+        if control_name is not None:
+            np.savetxt(control_name, self.u, fmt="%.5e")
+
+    def load(self, filename):
+        """sloshing.py:309-313: interior values of h and q, ghosts left at zero."""
+        f = np.loadtxt(filename)
+        init = np.zeros((2, self.nx + 2))
+        init[0, 1:self.nx + 1], init[1, 1:self.nx + 1] = f[:, 1], f[:, 2]
+        v = self.vec
+        v._init_np = init
+        v._init_dev = v._real(init, (2, self.nx + 2))
+
+    def warmup(self):
+        """Excitation warm-up of beacon/sloshing/init.py (signal(), n_warmup action steps)."""
+        t = 0.0
+        for _ in range(self.n_warmup):
+            self.vec.step(np.asarray([self.signal(t, self.dt_act)]))
+            t += self.dt_act
+
+
+class shkadov_separable(shkadov):
+    """shkadov/shkadov.py:376-481: round-robin per-jet view of shkadov -- the solver advances only
+    when the jet counter is 0; every call returns the 10 observations and the reward term of ONE
+    jet.  Host-side re-indexing of the batched kernel's outputs; no new numerics."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.observation_space = vec.Box(-1.0, 1.0, (self.n_obs,))
+        self.count = 0
+        self.act = np.zeros(self.n_jets)
+        self._obs_all = np.zeros(self.n_obs * self.n_jets)
+        self._blow = False
+
+    def _jet_rwd(self, i):
+        h = self.h
+        s = self.jet_pos + i * self.jet_space
+        d = h[s:s + self.l_rwd] - 1.0
+        return -(np.sum(np.square(d)) * self.dx) / (self.n_jets * self.l_rwd)
+
+    def _advance(self):
+        if self.count == self.n_jets - 1:
+            self.count = 0
+            return True
+        self.count += 1
+        return False
+
+    def reset(self):
+        if self.count == 0:
+            self._obs_all, _ = super().reset()
+            self._blow = False
+            self._stp_shadow = 0
+        obs = self._obs_all[self.count * self.n_obs:(self.count + 1) * self.n_obs].copy()
+        self._advance()
+        return obs, None
+
+    def step(self, u=None):
+        if self.count == 0:
+            if u is not None:
+                self.u = [float(x) for x in u]
+            self.vec.step(None if u is None else np.asarray(u, dtype=np.float64).reshape(1, -1), self._noise())
+            self.vec.set_stp(self._stp_shadow)            # the batched kernel counts solver steps;
+            self._obs_all = self._np(self.vec.obs)[0]      # the separable episode counter moves per round
+            self._blow = bool(int(self.vec.status[0].item()) & 2)
+        obs = self._obs_all[self.count * self.n_obs:(self.count + 1) * self.n_obs].copy()
+        rwd = self._jet_rwd(self.count)
+        done = trunc = (self._stp_shadow == self.n_act - 1)
+        if self._blow:
+            print("Blowup")
+            done, trunc, rwd = True, False, -1.0
+        if self._advance():
+            self._stp_shadow += 1
+            self.vec.set_stp(self._stp_shadow)
+        return obs, rwd, done, trunc, None
+
+    _stp_shadow = 0
+
+    @property
+    def stp(self):
+        return self._stp_shadow

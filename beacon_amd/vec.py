@@ -63,10 +63,10 @@ class VecEnv(object):
         self.tdtype, self.cdtype = _DT[dtype]
         self.h = C.c_void_p()
         self._create()
-        self.n_obs = self.lib.bcn_n_obs(self.h)
+        self.obs_dim = self.lib.bcn_n_obs(self.h)       # observation length per replica
         self.n_actions = self.lib.bcn_n_act(self.h)
         B = self.batch
-        self.obs = torch.zeros((B, self.n_obs), dtype=self.tdtype, device=self.device)
+        self.obs = torch.zeros((B, self.obs_dim), dtype=self.tdtype, device=self.device)
         self.rwd = torch.zeros((B,), dtype=self.tdtype, device=self.device)
         self.done = torch.zeros((B,), dtype=torch.uint8, device=self.device)
         self.trunc = torch.zeros((B,), dtype=torch.uint8, device=self.device)
@@ -136,14 +136,54 @@ class VecEnv(object):
             raise RuntimeError("Exceeded max number of iterations in solver (replicas %s)" % bad[:8].tolist())
         return st
 
+    # -- replica masks ----------------------------------------------------------------------
+    def _apply_mask(self, mask):
+        """mask: None (all replicas) or a [B] bool/uint8 tensor/array; replicas with 0 are skipped
+        by the next reset/step launch (their state and output rows stay as they are)."""
+        if mask is None:
+            self._mask = None
+            _lib.check(self.lib.bcn_set_mask(self.h, None))
+            return
+        if not torch.is_tensor(mask):
+            mask = torch.as_tensor(np.asarray(mask))
+        self._mask = mask.to(device=self.device, dtype=torch.uint8).reshape(self.batch).contiguous()
+        _lib.check(self.lib.bcn_set_mask(self.h, _ptr(self._mask)))
+
     # -- Gym surface ------------------------------------------------------------------------
-    def reset(self):
-        self._reset()
+    def reset(self, mask=None):
+        """Reset every replica, or only those selected by `mask` (what a trainer does when it calls
+        reset() on the one env whose episode ended)."""
+        self._apply_mask(mask)
+        try:
+            self._reset()
+        finally:
+            if mask is not None:
+                self._apply_mask(None)
         return self.obs, None
 
-    def step(self, actions=None, noise=None):
-        self._step(actions, noise)
+    def step(self, actions=None, noise=None, mask=None):
+        self._apply_mask(mask)
+        try:
+            self._step(actions, noise)
+        finally:
+            if mask is not None:
+                self._apply_mask(None)
         return self.obs, self.rwd, self.done, self.trunc, None
+
+    def reset_done(self):
+        """Auto-reset: re-initialise the replicas whose last step() returned done (their rows of
+        `obs` become the reset observation).  Entirely on the device, no host synchronisation."""
+        self._done_mask = self.done.clone()
+        return self.reset(mask=self._done_mask)
+
+    def warmup(self, n_steps, actions=None):
+        """Equivalent of the reference's init.py generators: n uncontrolled action steps
+        (zero / repeated action), e.g. to develop the flow from rest on a grid that ships no
+        init_field.dat.  Episode counters are reset afterwards."""
+        for _ in range(int(n_steps)):
+            self._step(actions, None)
+        self.set_stp(0)
+        return self.get_state()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -397,6 +437,20 @@ class VecShkadov(VecEnv):
     def draw_noise(self):
         r = torch.rand((self.batch, self.ndt_act), generator=self.gen, device=self.device, dtype=self.tdtype)
         return (2.0 * r - 1.0) * self.sigma
+
+    def reset_random(self, rand_steps=400, n_steps=None):
+        """reset() followed by a per-replica random number of uncontrolled steps, the batched form
+        of shkadov.reset with rand_init (shkadov.py:119-123: n = random.randint(0, rand_steps)).
+        n_steps: optional explicit int tensor [B]; drawn on the device otherwise."""
+        self.reset()
+        if n_steps is None:
+            n_steps = torch.randint(0, rand_steps + 1, (self.batch,), generator=self.gen, device=self.device)
+        n_steps = torch.as_tensor(n_steps).to(self.device)
+        self.n_rand = n_steps
+        for i in range(int(n_steps.max().item())):
+            self.step(None, None, mask=(n_steps > i))
+        self.set_stp(0)
+        return self.obs, None
 
     def _reset(self):
         _lib.check(self.lib.bcn_shkadov_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))

@@ -1,0 +1,105 @@
+"""vortex-v0: the reference's 4-variable Landau/oscillator model of vortex shedding coupled to a
+spring-mounted cylinder (vortex/vortex.py:18-260): unknowns (ar, ai, yr, yi), Box(2) action =
+(modulus, phase) of a proportional feedback, same low-storage RK4 as lorenz.  Host-only NumPy, like
+beacon_amd.lorenz: an ODE with 4 unknowns has nothing to put on a GPU."""
+import math
+
+import numpy as np
+
+from .lorenz import _A, _B
+from .vec import Box
+
+
+class vortex(object):
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, cpu=0, re=50.0, weight=50.0):
+        # model constants (vortex.py:26-42)
+        self.lmbda_re, self.lmbda_cx = 9.153, 3.239
+        self.mu_re, self.mu_cx = 308.9, -1025.0
+        self.alpha_re, self.alpha_cx = 0.03492, 0.01472
+        self.beta, self.re, self.re_crit = 1.0, re, 46.6
+        self.ire = 1.0 / self.re_crit - 1.0 / self.re
+        self.omega_s, self.omega_f = 1.1, 0.74
+        self.domega = self.omega_s - self.omega_f
+        self.gamma, self.mass, self.weight = 0.023, 10.0, weight
+        self.beta_m = self.beta / (self.omega_f * self.mass)
+        self.dt, self.dt_act, self.t_max = 0.1, 0.5, 400.0
+        self.n_obs = 8
+        self.ndt_act = int(self.dt_act / self.dt)
+        self.n_act = int(self.t_max / self.dt_act)
+        self.mod_min, self.mod_max = 0.0, 0.3
+        self.phase_min, self.phase_max = -math.pi, math.pi
+        self.x, self.xk, self.fx = np.zeros(4), np.zeros(4), np.zeros(4)
+        self.action_space = Box(-1.0, 1.0, (2,))
+        self.observation_space = Box(-1.0e-4, 1.0e-4, (self.n_obs,))
+        self.reset_fields()
+
+    def _y(self):
+        return 2.0 * (self.x[2] * math.cos(self.omega_f * self.t) - self.x[3] * math.sin(self.omega_f * self.t))
+
+    def reset_fields(self):
+        self.t = 0.0
+        self.x[:] = (-0.00385, -0.00378, 0.00118, -0.00131)
+        self.y = self._y()
+        self.xk[:] = 0.0
+        self.fx[:] = 0.0
+        self.u = np.zeros(2)
+        self.kmod = self.kphase = 0.0
+        self.hx, self.ht = [self.x.copy()], [self.t]
+        self.stp = 0
+
+    def reset(self):
+        self.reset_fields()
+        return self.get_obs(), None
+
+    def get_obs(self):
+        return np.concatenate([self.x, self.fx])
+
+    def solve(self, u=None):
+        if u is None:
+            u = self.u
+        self.u = np.array(u, dtype=np.float64)
+        self.kmod = self.mod_min + 0.5 * (self.u[0] + 1.0) * (self.mod_max - self.mod_min)
+        self.kphase = self.phase_min + 0.5 * (self.u[1] + 1.0) * (self.phase_max - self.phase_min)
+        x, xk, fx = self.x, self.xk, self.fx
+        for _ in range(self.ndt_act):
+            xk[:] = x
+            for j in range(5):
+                ar, ai, yr, yi = xk
+                m2 = ar ** 2 + ai ** 2
+                fx[0] = (self.ire * (self.lmbda_re * ar - self.lmbda_cx * ai) - (self.mu_re * ar - self.mu_cx * ai) * m2 +
+                         (self.alpha_re * yr - self.alpha_cx * yi) + ar * self.kmod * math.cos(self.kphase) -
+                         ai * self.kmod * math.sin(self.kphase))
+                fx[1] = (self.ire * (self.lmbda_re * ai + self.lmbda_cx * ar) - (self.mu_re * ai + self.mu_cx * ar) * m2 +
+                         (self.alpha_re * yi + self.alpha_cx * yr) + ar * self.kmod * math.sin(self.kphase) +
+                         ai * self.kmod * math.cos(self.kphase))
+                fx[2] = -self.omega_f * self.gamma * yr - self.domega * yi + self.beta_m * ar
+                fx[3] = -self.omega_f * self.gamma * yi + self.domega * yr + self.beta_m * ai
+                for i in range(4):
+                    x[i] = _A[j] * x[i] + self.dt * fx[i]
+                    xk[i] += _B[j] * x[i]
+            x[:] = xk
+            self.t += self.dt
+            self.hx.append(x.copy())
+            self.ht.append(self.t)
+
+    def get_rwd(self):
+        self.yp = self.y
+        self.y = self._y()
+        c, s = math.cos(self.omega_f * self.t), math.sin(self.omega_f * self.t)
+        cost = (2.0 * self.kmod * math.cos(self.kphase) * (self.x[0] * c - self.x[1] * s) -
+                2.0 * self.kmod * math.sin(self.kphase) * (self.x[1] * c + self.x[0] * s))
+        cost = 0.5 * cost ** 2
+        rwd = 2.0 * self.omega_s * self.gamma * ((self.y - self.yp) / self.dt) ** 2
+        return rwd - self.weight * cost
+
+    def step(self, u=None):
+        self.solve(u)
+        obs, rwd = self.get_obs(), self.get_rwd()
+        done = trunc = (self.stp == self.n_act - 1)
+        self.stp += 1
+        return obs, rwd, done, trunc, None
+
+    def close(self):
+        pass

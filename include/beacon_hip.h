@@ -157,6 +157,12 @@ BCN_API int bcn_n_act(bcn_env_t h);       /* action length per replica */
 BCN_API size_t bcn_state_elems(bcn_env_t h);
 BCN_API int bcn_get_state(bcn_env_t h, void* buf, int is_device, void* stream);
 BCN_API int bcn_set_state(bcn_env_t h, const void* buf, int is_device, void* stream);
+/* Replica mask for the calls that follow: *_reset and *_step skip every replica b with mask_dev[b] == 0
+ * (state, stp and that replica's rows of the output buffers stay untouched); NULL = all replicas.  The
+ * pointer is read at launch time of each later call, so it must stay valid.  Used for per-replica
+ * resets at episode end (the reference's trainer calls reset() on one env) and for the per-env random
+ * number of uncontrolled warm-up steps of shkadov.reset (shkadov.py:119-123). */
+BCN_API int bcn_set_mask(bcn_env_t h, const uint8_t* mask_dev);
 /* episode counter `stp` of every replica (rayleigh.py:126,155): int32[B] */
 BCN_API int bcn_get_stp(bcn_env_t h, int32_t* buf_host, void* stream);
 BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);

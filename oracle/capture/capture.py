@@ -426,7 +426,47 @@ def job_init_data():
     print("wrote", path, ray.shape, shk.shape, slo.shape)
 
 
+def job_vortex():
+    mod, d = load_ref("vortex")
+    out = {}
+    for tag in ("zero", "rnd"):
+        s = mod.vortex()
+        obs0, _ = s.reset()
+        obs0 = obs0.copy()
+        n = s.n_act if tag == "zero" else 120
+        acts = np.zeros((n, 2)) if tag == "zero" else np.random.default_rng(500).uniform(-1.0, 1.0, (n, 2))
+        obs, rwd, dn = [], [], []
+        for k in range(n):
+            o, r, done, trunc, _ = s.step(acts[k].copy())
+            obs.append(o.copy()), rwd.append(r), dn.append([done, trunc])
+        out.update({tag + "_reset_obs": obs0, tag + "_actions": acts, tag + "_obs": np.array(obs),
+                    tag + "_rwd": np.array(rwd), tag + "_done": np.array(dn), tag + "_hx": s.hx.copy()})
+    save("vortex", **out)
+
+
+def job_shkadov_separable():
+    """shkadov_separable (shkadov.py:376-481): 5 round-robin resets, then 3 rounds of 5 per-jet steps."""
+    mod, d = load_ref("shkadov")
+    with cwd(d):
+        s = mod.shkadov_separable(n_jets=5)
+    s.rand_init = False
+    robs = [s.reset()[0].copy() for _ in range(5)]
+    acts = np.random.default_rng(600).uniform(-1.0, 1.0, (3, 5))
+    seed = 6
+    np.random.seed(seed)
+    obs, rwd, dn, stp = [], [], [], []
+    for r in range(3):
+        for j in range(5):
+            o, rw, done, trunc, _ = s.step(acts[r].tolist())
+            obs.append(o.copy()), rwd.append(rw), dn.append([done, trunc]), stp.append(s.stp)
+    save("shkadov_separable", reset_obs=np.array(robs), actions=acts, obs=np.array(obs), rwd=np.array(rwd),
+         done=np.array(dn), stp=np.array(stp), noise=noise_stream(seed, s.sigma, 3 * s.ndt_act).reshape(3, s.ndt_act),
+         h=s.h.copy(), q=s.q.copy())
+
+
 JOBS = {
+    "shkadov_separable": job_shkadov_separable,
+    "vortex": job_vortex,
     "init_data": job_init_data,
     "rayleigh_default": job_rayleigh_default,
     "rayleigh_128x64": job_rayleigh_128x64,

@@ -159,3 +159,18 @@ def test_replica_sharding_collectives_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def test_vortex_host_env_matches_reference_episodes():
+    import beacon_amd
+    g = golden("vortex")
+    for tag in ("zero", "rnd"):
+        e = beacon_amd.vortex()
+        o0, info = e.reset()
+        assert info is None and np.array_equal(o0, g[tag + "_reset_obs"])
+        for k, a in enumerate(g[tag + "_actions"]):
+            o, r, d, t, info = e.step(a)
+            assert np.array_equal(o, g[tag + "_obs"][k]) and r == g[tag + "_rwd"][k]
+            assert [d, t] == g[tag + "_done"][k].tolist()
+        assert np.array_equal(np.array(e.hx), g[tag + "_hx"])
+    assert e.action_space.shape == (2,) and e.observation_space.shape == (8,)
