@@ -34,7 +34,7 @@ struct NS2DEnv : bcn_env_s {
   NS2DArgs<real> a{};
   DevBuf fields;    // u,v,p,S,us,vs   [6][B][ncell]
   DevBuf work;      // g0,g1,g2        [3][B][ncell]  (only when the work arrays do not fit LDS)
-  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf;
+  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf, schedbuf;
   bool fast_ok = false;
 
   int init() {
@@ -68,6 +68,8 @@ struct NS2DEnv : bcn_env_s {
     a.sweeps_int = static_cast<int32_t*>(sweepbuf.p);
     if ((rc = orderbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
     a.order_out = static_cast<int32_t*>(orderbuf.p);
+    if ((rc = schedbuf.alloc(128 + (size_t)batch * sizeof(uint32_t)))) return rc;
+    a.sched_ctl = schedbuf.p;
     fast_ok = ns2d_fast_supported<real>(a);
     variant = fast_ok ? 1 : 0;
     return BCN_OK;
@@ -75,7 +77,7 @@ struct NS2DEnv : bcn_env_s {
   ~NS2DEnv() override {
     DeviceGuard g(device);
     fields.release(); work.release(); obs_hist.release(); a_last.release(); ia_last.release();
-    stpbuf.release(); sweepbuf.release(); orderbuf.release();
+    stpbuf.release(); sweepbuf.release(); orderbuf.release(); schedbuf.release();
   }
   size_t state_elems() const override { return 4 * (size_t)a.ncell; }
   // state buffer layout: [B][4][ncell]; device layout: [4][B][ncell]

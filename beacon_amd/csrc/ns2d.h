@@ -47,6 +47,8 @@ struct NS2DArgs {
   const int32_t* order;     // blockIdx -> replica, or NULL for identity
   int32_t* order_out;       // rank kernel output
   int32_t* sweeps_int;      // handle-owned [B][ndt_act] when the caller passes no sweeps buffer
+  void* sched_ctl;          // handle-owned control block of the ticketed chunk scheduler (64 + 4B bytes)
+  int sched_q;              // timesteps per chunk
 };
 
 // launchers (one per translation unit)

@@ -104,7 +104,7 @@ struct FastGeom {
   // LDS map (elements): [ exchange 2*NW*2*64 | errp 32 | sact 64 | red 32 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
-  static constexpr int MISC = 2 * NW * 2 * 64 + 128;
+  static constexpr int MISC = 2 * NW * 2 * 64 + 128 + 16;   // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + PD + 1) * SY;
   static constexpr size_t lds_elems() { return (size_t)FRONT + 3 * (size_t)SZ + BACK; }
@@ -173,11 +173,12 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
 #undef BCN_CHAIN
     }
 
+// One unit of work: timesteps [it_begin, it_end) of replica b (state HBM -> chip -> HBM).
 template <typename real, int NX, int NY, int R, int KIND, bool EQ>
-__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
+__device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
+                                          const bool first_chunk, const bool last_chunk, char* smem) {
   using G = FastGeom<NX, NY, R>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
   real* errp = exch + 2 * NW * 2 * 64;         // [2][16]
   real* sact = errp + 32;                      // [64]
@@ -186,8 +187,6 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
   real* Vl = Ul + SZ;
   real* Tl = Vl + SZ;
 
-  const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
-  if (A.mask && !A.mask[b]) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane + 1;
   const bool active = lane < NY;
@@ -213,7 +212,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
   for (int k = 0; k < R; k++) p[k] = active ? gp[j * SX + i0 + k] : real(0);
 
   // ---- action conditioning (rayleigh.py:162-171); later chunks reuse the conditioned vector ----
-  if (!A.first_chunk) {
+  if (!first_chunk) {
     if (tid < A.n_sgts) sact[tid] = A.a_last[(size_t)b * A.n_sgts + tid];
   } else {
     const int n = A.n_sgts;
@@ -256,8 +255,8 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
 #else
 #define BCN_PH(x)
 #endif
-  if (!A.first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
-  for (int it = A.it_begin; it < A.it_end && status == 0; it++) {
+  if (!first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
+  for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
       Ul[1 * SY + jj] = 0;
@@ -504,14 +503,98 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
     const unsigned long long kt1 = __builtin_amdgcn_s_memtime(), kr1 = __builtin_amdgcn_s_memrealtime();
     status = (int)((kt1 - kt0) * 100ull / (kr1 - kr0 + 1));
     if (tid == 0 && A.actions_norm)
-      for (int q = 0; q < 6; q++) A.actions_norm[(size_t)b * A.n_sgts + q] = (real)seg[q] / (real)(A.it_end - A.it_begin);
+      for (int q = 0; q < 6; q++) A.actions_norm[(size_t)b * A.n_sgts + q] = (real)seg[q] / (real)(it_end - it_begin);
 
   }
 #endif
-  if (A.last_chunk) {
+  if (last_chunk) {
     ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
   } else if (tid == 0 && A.status) {
     A.status[b] = status;
+  }
+}
+
+// plain launch: one workgroup per replica, timesteps [A.it_begin, A.it_end)
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
+  fast_unit<real, NX, NY, R, KIND, EQ>(A, b, A.it_begin, A.it_end, A.first_chunk != 0, A.last_chunk != 0, smem);
+}
+
+// ---- ticketed chunk scheduler ----------------------------------------------------------------
+// With more replicas than CUs a replica is no longer tied to one workgroup: the step is cut into
+// chunks of A.sched_q timesteps and persistent workgroups (one per CU) draw (chunk, replica) units
+// from a global ticket counter in chunk-major order, so every CU stays busy until the slowest
+// replica's chain of chunks ends (makespan ~ max(critical path, mean) instead of the sum of whichever
+// two replicas a CU happened to get).  A replica's state moves between CUs through HBM; the hand-off
+// follows the agent-scope release/acquire recipe of the CDNA programming guide (Guideline 16):
+//   producer: stores -> workgroup barrier -> lane 0: fence(release, agent); s_waitcnt vmcnt(0);
+//             relaxed agent store progress[r] = c+1
+//   consumer: lane 0 polls progress[r] (relaxed, agent, s_sleep) -> fence(acquire, agent);
+//             s_waitcnt vmcnt(0) -> workgroup barrier -> plain loads.
+// Tickets are drawn in order, so when unit (c, r) is drawn unit (c-1, r) has already been drawn by
+// a workgroup that never waits on a later ticket: every wait is finite whatever the residency.
+// Spins are bounded anyway: on timeout the abort word is set, every workgroup drains, and the
+// affected replicas report BCN_ST_ITMAX.
+struct SchedCtl {
+  unsigned int ticket;
+  unsigned int abort;
+  unsigned int pad[14];
+  unsigned int progress[1];   // [B]
+};
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
+  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
+                                                          2 * FastGeom<NX, NY, R>::NW * 2 * 64 + 128);
+  unsigned int& s_ticket = s_words[0];
+  unsigned int& s_ok = s_words[1];
+  const unsigned int total = (unsigned int)batch * (unsigned int)nchunk;
+  for (;;) {
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const unsigned int t = s_ticket;
+    if (t >= total) break;
+    const int c = (int)(t / (unsigned int)batch), b = (int)(t % (unsigned int)batch);
+    const bool skip = A.mask && !A.mask[b];
+    if (threadIdx.x == 0) {
+      unsigned int ok = 1;
+      if (!skip && c > 0) {
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&ctl->progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)c) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > (1u << 24) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      s_ok = ok;
+    }
+    __syncthreads();
+    if (!skip) {
+      if (s_ok) {
+        const int it0 = c * A.sched_q;
+        const int it1 = (c == nchunk - 1) ? A.ndt_act : it0 + A.sched_q;
+        fast_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, c == 0, c == nchunk - 1, smem);
+      } else if (threadIdx.x == 0 && A.status) {
+        A.status[b] = BCN_ST_ITMAX;
+      }
+      __syncthreads();   // every wave's stores are issued and waited for (barrier implies vmcnt(0))
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctl->progress[b], (unsigned int)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();     // s_ticket / s_ok are rewritten next trip
   }
 }
 
@@ -551,6 +634,32 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
+  // ---- scheduling mode: BCN_SCHED = 0 plain launch, 1 two-launch LPT split, 2 ticketed chunks (default)
+  static int mode = -1, sched_grid = 0, ncu_dev = 256;
+  if (mode < 0) {
+    const char* e = getenv("BCN_SCHED");
+    const char* g = getenv("BCN_SCHED_GRID");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, dev);
+    sched_grid = g ? atoi(g) : ncu_dev;
+    mode = e ? atoi(e) : 2;
+  }
+  constexpr int SQ = 10;
+  if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
+    auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ>;
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+      BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set2 = true;
+    }
+    const int nchunk = a.ndt_act / SQ;
+    c.sched_q = SQ; c.order = nullptr; c.first_chunk = 1; c.last_chunk = 1; c.it_begin = 0; c.it_end = a.ndt_act;
+    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, sizeof(SchedCtl) + (size_t)batch * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(ks, dim3(sched_grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
+    BCN_HIP(hipGetLastError());
+    return BCN_OK;
+  }
   // split only when replicas outnumber the CUs (otherwise every replica starts at once and
   // the order cannot matter); BCN_LPT_MIN_BATCH overrides the threshold (tests)
   static int min_batch = -1;
@@ -562,7 +671,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     min_batch = e ? atoi(e) : ncu + 1;
   }
   constexpr int Q = 10;
-  const bool split = batch >= min_batch && batch <= 2048 && a.ndt_act >= 4 * Q;
+  const bool split = mode >= 1 && batch >= min_batch && batch <= 2048 && a.ndt_act >= 4 * Q;
   c.first_chunk = 1; c.order = nullptr; c.it_begin = 0;
   if (!split) {
     c.it_end = a.ndt_act; c.last_chunk = 1;

@@ -135,7 +135,7 @@ def test_rayleigh_batch_vs_oracle_f64(variant):
     env.close()
 
 
-def test_rayleigh_fast_two_launch_lpt_matches_single_launch():
+def test_rayleigh_fast_schedulers_match_single_launch():
     """The fast path splits a step into [0,Q) + LPT-ordered [Q,ndt) when replicas outnumber
     the CUs; forced here on a small batch: obs, rewards, sweep counts and interior fields must
     equal the unsplit run bit for bit (only the p ghost cells, rebuilt once per launch from the
@@ -157,20 +157,22 @@ def test_rayleigh_fast_two_launch_lpt_matches_single_launch():
         " env.get_state().cpu().numpy().ravel(), env.sweeps.cpu().numpy().ravel().astype(float)]))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tag, minb in (("split", "2"), ("single", "100000")):
+    for tag, extra in (("split", dict(BCN_SCHED="1", BCN_LPT_MIN_BATCH="2")), ("single", dict(BCN_SCHED="0")),
+                       ("ticket", dict(BCN_SCHED="2", BCN_SCHED_GRID="5"))):
         path = "/tmp/bcn_lpt_%s.npy" % tag
-        env = dict(os.environ, BCN_LPT_MIN_BATCH=minb)
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
     n_obs, B = 24 * 192, 24
-    assert np.array_equal(outs[0][:n_obs + B], outs[1][:n_obs + B])                  # obs, rwd
-    assert np.array_equal(outs[0][-B * 200:], outs[1][-B * 200:])                    # sweeps
-    st = [o[n_obs + B:-B * 200].reshape(B, 4, 52, 52) for o in outs]
-    for f in (0, 1, 3):
-        assert np.array_equal(st[0][:, f], st[1][:, f])
-    assert np.array_equal(st[0][:, 2, 1:-1, 1:-1], st[1][:, 2, 1:-1, 1:-1])
-    assert np.max(np.abs(st[0][:, 2] - st[1][:, 2])) < 1e-13
+    for other in (outs[0], outs[2]):      # two-launch LPT split / ticketed chunk scheduler (5 persistent WGs) vs plain
+        assert np.array_equal(other[:n_obs + B], outs[1][:n_obs + B])                  # obs, rwd
+        assert np.array_equal(other[-B * 200:], outs[1][-B * 200:])                    # sweeps
+        st = [o[n_obs + B:-B * 200].reshape(B, 4, 52, 52) for o in (other, outs[1])]
+        for f in (0, 1, 3):
+            assert np.array_equal(st[0][:, f], st[1][:, f])
+        assert np.array_equal(st[0][:, 2, 1:-1, 1:-1], st[1][:, 2, 1:-1, 1:-1])
+        assert np.max(np.abs(st[0][:, 2] - st[1][:, 2])) < 1e-12
 
 
 def test_rayleigh_episode_end_and_overflow():
