@@ -28,6 +28,9 @@
 #ifndef BCN_R128
 #define BCN_R128 8
 #endif
+#ifndef BCN_LAG
+#define BCN_LAG 0   // lagged convergence test: measured no faster (1556 vs 1555 cycles per sweep), kept for reference
+#endif
 
 namespace {
 
@@ -49,22 +52,24 @@ template <typename real> __device__ __forceinline__ real from_below(real oldv, r
 // value of the lane above (row j+1); lane 63 keeps `oldv`
 template <typename real> __device__ __forceinline__ real from_above(real oldv, real v) { return dpp<0x130, 0xf, 0xf, false>(oldv, v); }
 
-// acc + (value of the lane above / below, 0 outside the wave) as ONE v_add_f32_dpp.  hipcc fuses the
-// DPP move into the add only for some of the stencil cells; the asm form makes it unconditional.
-// Safe w.r.t. the VALU-write -> DPP-read hazard (2 wait states) as used here: the DPP source is a
-// phi register written a whole half-sweep earlier.
-__device__ __forceinline__ float add_above(float acc, float c) {
-  float r;
-  asm("v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(c), "v"(acc));
+// acc + north + south neighbour (values of the lanes above and below, 0 outside the wave) as two
+// fused v_add_f32_dpp.  hipcc fuses the DPP move into the add only for some of the stencil cells, so
+// the pair is spelled out.  hipcc does not model instructions inside an asm statement: it once
+// scheduled the VALU write of `c` directly in front of this statement (VALU write -> DPP read of the
+// same VGPR needs 2 wait states; symptom: replicas with identical inputs diverged), hence the
+// leading s_nop 1.  The second add reads `c` by DPP again and `t` as a plain operand: no hazard.
+__device__ __forceinline__ float add_above_below(float acc, float c) {
+  float t, r;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(t), "=v"(r)
+      : "v"(c), "v"(acc));
   return r;
 }
-__device__ __forceinline__ float add_below(float acc, float c) {
-  float r;
-  asm("v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(c), "v"(acc));
-  return r;
+__device__ __forceinline__ double add_above_below(double acc, double c) {
+  return acc + dpp<0x130, 0xf, 0xf, true>(0.0, c) + dpp<0x138, 0xf, 0xf, true>(0.0, c);
 }
-__device__ __forceinline__ double add_above(double acc, double c) { return acc + dpp<0x130, 0xf, 0xf, true>(0.0, c); }
-__device__ __forceinline__ double add_below(double acc, double c) { return acc + dpp<0x138, 0xf, 0xf, true>(0.0, c); }
 
 template <typename real>
 __device__ __forceinline__ real row16_sum(real s) {  // lane 15 of each 16-lane row: sum of the row
@@ -350,21 +355,12 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     // R-2 interior cells of the NEXT sweep are computed while they are in flight; only then is
     // the convergence test of the finished sweep evaluated (if it passes, the partial next
     // sweep is simply dropped) and the two edge cells are completed.
-    real phA[R], phB[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) phA[k] = 0;
-    real hW = 0, hE = 0;            // halos of the current source array
-    real eL = 0, hWr = 0, hEr = 0;  // LDS reads in flight
-    int itp = 0;
-    bool finalB = false;
-    const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
     auto cell = [&](real c, real e, real wv, real nbk) -> real {
       const real q = cBy * c + nbk;                       // Neumann ghosts in y copy the cell itself
       real ph;
       if (EQ) {
         real sum = e + wv;
-        sum = add_above(sum, c);                          // north (lane+1); 0 past the last lane
-        sum = add_below(sum, c);                          // south (lane-1); 0 below lane 0
+        sum = add_above_below(sum, c);                    // + north (lane+1) + south (lane-1); 0 outside the wave
         ph = cx * sum + q;
       } else {
         const real ns = dpp<0x130, 0xf, 0xf, true>(real(0), c) + dpp<0x138, 0xf, 0xf, true>(real(0), c);
@@ -373,9 +369,78 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       if (NY < 64) ph *= actf;                            // lanes past the top row stay 0
       return ph;
     };
+    const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
+    real hW = 0, hE = 0;            // halos of the current source array
+    real eL = 0, hWr = 0, hEr = 0;  // LDS reads in flight
+    int itp = 0;
 #ifdef BCN_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
+#if BCN_LAG
+    // Lagged convergence test: phi rotates through THREE register arrays; the error norm of sweep
+    // n is reduced and published while sweep n+1 runs and is tested during sweep n+2, so the
+    // reduction chain and its LDS round trip are off the barrier-to-barrier critical path.  When
+    // the test passes, the array holding phi_n is still intact (at most ~1.75 sweeps are dropped)
+    // and `hW` still holds its west halo for the corrector.  Sweep counts are unchanged.
+    real phA[R], phB[R], phC[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) { phA[k] = 0; phB[k] = 0; phC[k] = 0; }
+    real accPrev = 0;               // weighted error partial of the previous sweep (per lane)
+    int nsw = 0;                    // sweeps started
+    int fin = 0;                    // which array holds the result
+#define BCN_SWEEP(SRC, DST, OLD_IDX)                                                         \
+    {                                                                                        \
+      nsw++;                                                                                 \
+      real acc = 0;                                                                          \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                    \
+        const real ph = cell(SRC[k], SRC[k + 1], SRC[k - 1], nb[k]);                         \
+        const real d = ph - SRC[k];                                                          \
+        acc += d * d;                                                                        \
+        DST[k] = ph;                                                                         \
+      }                                                                                      \
+      if (nsw >= 3) {                                                                        \
+        const real err = read_lane(row16_sum<real>(eL), 15);      /* of sweep nsw-2 */       \
+        itp = nsw - 2;                                                                       \
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; fin = OLD_IDX; break; }                 \
+        if (!(err > A.tol)) { fin = OLD_IDX; break; }                                        \
+      }                                                                                      \
+      if (nsw >= 2) {                                                                        \
+        hW = (w > 0) ? hWr : SRC[0];                                                         \
+        hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                \
+        const real tot63 = wave_sum_lane63<real>(accPrev);        /* of sweep nsw-1 */       \
+        if (lane == 63) errp[xb * 16 + w] = tot63;                                           \
+      }                                                                                      \
+      const real p0 = cell(SRC[0], SRC[1], hW, nb[0]);                                       \
+      const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
+      const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
+      DST[0] = p0;                                                                           \
+      DST[R - 1] = pl;                                                                       \
+      ex(xb, w, 0)[lane] = p0;                                                               \
+      ex(xb, w, 1)[lane] = pl;                                                               \
+      acc += d0 * d0;                                                                        \
+      acc += dl * dl;                                                                        \
+      accPrev = wl * acc + fW * (d0 * d0) + fE * (dl * dl);                                  \
+      __syncthreads();                                                                       \
+      eL = errp[xb * 16 + (lane & 15)];                                                      \
+      hWr = ex(xb, wm, 1)[lane];                                                             \
+      hEr = ex(xb, wp, 0)[lane];                                                             \
+      xb ^= 1;                                                                               \
+    }
+    for (;;) {
+      BCN_SWEEP(phA, phB, 2)
+      BCN_SWEEP(phB, phC, 0)
+      BCN_SWEEP(phC, phA, 1)
+    }
+#undef BCN_SWEEP
+    if (fin != 0) {
+#pragma unroll
+      for (int k = 0; k < R; k++) phA[k] = (fin == 1) ? phB[k] : phC[k];
+    }
+#else
+    real phA[R], phB[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) phA[k] = 0;
+    bool finalB = false;
 #define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                        \
     {                                                                                        \
       real acc = 0;                                                                          \
@@ -419,6 +484,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #pragma unroll
       for (int k = 0; k < R; k++) phA[k] = phB[k];
     }
+#endif
 #ifdef BCN_STAMP   // diagnostic build only: cycles per sweep in the high half of the sweep count
     {
       const unsigned long long st1 = __builtin_amdgcn_s_memtime();
@@ -635,17 +701,18 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
   // ---- scheduling mode: BCN_SCHED = 0 plain launch, 1 two-launch LPT split, 2 ticketed chunks (default)
-  static int mode = -1, sched_grid = 0, ncu_dev = 256;
+  static int mode = -1, sched_grid = 0, ncu_dev = 256, SQ = 10;
   if (mode < 0) {
     const char* e = getenv("BCN_SCHED");
     const char* g = getenv("BCN_SCHED_GRID");
+    const char* q = getenv("BCN_SCHED_Q");
+    if (q && atoi(q) > 0) SQ = atoi(q);
     int dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, dev);
     sched_grid = g ? atoi(g) : ncu_dev;
     mode = e ? atoi(e) : 2;
   }
-  constexpr int SQ = 10;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
     auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ>;
     static bool attr_set2 = false;

@@ -9,7 +9,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, ref_to_dev
+import os
+
+from conftest import GOLD, golden, ref_to_dev
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -173,6 +175,27 @@ def test_rayleigh_fast_schedulers_match_single_launch():
             assert np.array_equal(st[0][:, f], st[1][:, f])
         assert np.array_equal(st[0][:, 2, 1:-1, 1:-1], st[1][:, 2, 1:-1, 1:-1])
         assert np.max(np.abs(st[0][:, 2] - st[1][:, 2])) < 1e-12
+
+
+@pytest.mark.parametrize("cfg,dtype", [("50", "f32"), ("50", "f64"), ("128", "f32")])
+def test_rayleigh_fast_identical_replicas_are_bit_identical(cfg, dtype):
+    """Race / hazard detector: 96 replicas with identical inputs must stay bit-identical, sweep counts
+    included (a missing wait state in front of a hand-written DPP instruction once showed up exactly
+    here, and nowhere else)."""
+    B = 96
+    if cfg == "50":
+        env = V.VecRayleigh(B, DEV, dtype, E.packaged_init("rayleigh"))
+    else:
+        env = V.VecRayleigh(B, DEV, dtype, np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"], L=2.56, H=1.28)
+    _variant(env, 1)
+    env.reset()
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        obs, *_ = env.step(np.tile(rng.uniform(-1, 1, (1, 10)), (B, 1)))
+        st, sw = env.get_state(), env.sweeps
+        assert int((st != st[0:1]).flatten(1).any(1).sum()) == 0
+        assert int((sw != sw[0:1]).any(1).sum()) == 0
+    env.close()
 
 
 def test_rayleigh_episode_end_and_overflow():
