@@ -16,6 +16,8 @@
 //    NEW values of (i-1,j) and (i,j-1).  It is linear in those two, so it is evaluated as
 //    S' = A + aW*S'(i-1,j) + aS*S'(i,j-1) along anti-diagonals d = i+j (cells of one diagonal
 //    are independent); A, aW, aS are computed for all cells in parallel first.
+#include <stdlib.h>
+
 #include "ns2d.h"
 #include "ns2d_device.h"
 
@@ -146,41 +148,139 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
     __syncthreads();
 
     // ---- Poisson rhs (recomputed every sweep in the reference, rayleigh.py:424-426) ----
-    for (int j = 1 + ty; j <= ny; j += NW)
-      for (int i = 1 + tx; i <= nx; i += BCN_WAVE) {
-        const int c = j * sx + i;
-        W2[c] = A.cb * ((us[c + 1] - us[c]) * A.rdx + (vs[c + sx] - vs[c]) * A.rdy);
-        W0[c] = 0;
-      }
-    __syncthreads();
-
-    // ---- Jacobi sweeps (rayleigh.py:419-454 / mixing.py:428-463) ----
     real* src = W0;
     real* dst = W1;
     int itp = 0;
     real err;
-    do {
-      real loc = 0;
-      for (int j = 1 + ty; j <= ny; j += NW) {
-        const int jS = (j > 1) ? j - 1 : 1;
-        const bool top = (j == ny);
-        for (int i = 1 + tx; i <= nx; i += BCN_WAVE) {
-          const int iW = (i > 1) ? i - 1 : 1, iE = (i < nx) ? i + 1 : nx;
-          const int c = j * sx + i;
-          real pN = top ? (A.kind == 0 ? src[c] : real(0)) : src[c + sx];
-          real ph = A.cx * (src[j * sx + iE] + src[j * sx + iW]) + A.cy * (pN + src[jS * sx + i]) - W2[c];
-          real d = ph - src[c];
-          real w = real(1) + (i == 1 ? 1 : 0) + (i == nx ? 1 : 0) + (j == 1 ? 1 : 0) +
-                   ((top && A.kind == 0) ? 1 : 0);
-          loc += w * d * d;
-          dst[c] = ph;
+    // Every thread owns at most NA x NB cells (i = 1+tx+64a, j = 1+ty+NW b).  When the grid fits
+    // these static slots, a cell's centre value, rhs and error weight stay in registers and the
+    // ghost cells of the destination buffer are written by the owners of the edge cells (the
+    // reference copies them after each sweep), so the inner loop is 4 LDS reads + 1 write with
+    // no index clamping.  Larger grids take the clamped loop below.
+    constexpr int NA = 2, NB = 8;
+    constexpr bool REGS = NT <= 256;      // 1024 threads leave 128 VGPRs: slots in registers would spill
+    if (LDSW && nx <= NA * BCN_WAVE && ny <= NB * NW) {
+      real pc[REGS ? NB : 1][NA], rh[REGS ? NB : 1][NA];
+      for (int c = tid; c < A.ncell; c += NT) { W0[c] = 0; W1[c] = 0; }
+#pragma unroll
+      for (int bb = 0; bb < NB; bb++)
+#pragma unroll
+        for (int aa = 0; aa < NA; aa++) {
+          const int jj = 1 + ty + NW * bb, ii = 1 + tx + BCN_WAVE * aa;
+          const bool valid = (jj <= ny) && (ii <= nx);
+          const int c = valid ? jj * sx + ii : sx + 1;
+          const real r = valid ? A.cb * ((us[c + 1] - us[c]) * A.rdx + (vs[c + sx] - vs[c]) * A.rdy) : real(0);
+          if constexpr (REGS) { rh[bb][aa] = r; pc[bb][aa] = 0; }
+          else if (valid) W2[c] = r;
         }
-      }
-      err = block_sum<real, NT>(loc, red + (itp & 1) * NW);
-      itp++;
-      real* t = src; src = dst; dst = t;
-      if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
-    } while (err > A.tol);
+      // error weights (ghosts copy their interior neighbour): 1 + one per Neumann side the cell touches
+      const int aE = (nx - 1) / BCN_WAVE;                              // slot column that holds i == nx
+      const real wW = (tx == 0) ? real(1) : real(0);                   // i == 1  (slot column 0)
+      const real wE = (tx == (nx - 1) % BCN_WAVE) ? real(1) : real(0); // i == nx (slot column aE)
+      __syncthreads();
+      do {
+        real loc = 0;
+#pragma unroll
+        for (int bb = 0; bb < NB; bb++) {
+          const int jj = 1 + ty + NW * bb;          // wave-uniform
+          if (jj <= ny) {
+            const real wrow = real(1) + (jj == 1 ? 1 : 0) + ((jj == ny && A.kind == 0) ? 1 : 0);
+#pragma unroll
+            for (int aa = 0; aa < NA; aa++) {
+              const int ii = 1 + tx + BCN_WAVE * aa;
+              if (ii <= nx) {
+                const int c = jj * sx + ii;
+                const real rhs = REGS ? rh[REGS ? bb : 0][aa] : W2[c];
+                const real cen = REGS ? pc[REGS ? bb : 0][aa] : src[c];
+                const real ph = A.cx * (src[c + 1] + src[c - 1]) + A.cy * (src[c + sx] + src[c - sx]) - rhs;
+                const real d = ph - cen;
+                const real w = wrow + (aa == 0 ? wW : real(0)) + (aa == aE ? wE : real(0));
+                loc += w * d * d;
+                if constexpr (REGS) pc[bb][aa] = ph;
+                dst[c] = ph;
+              }
+            }
+          }
+        }
+        // ghost cells of dst = copies of the adjacent new interior values (0 on mixing's top wall),
+        // written by the threads that own the edge cells, outside the hot loop
+        if (tx == 0 || tx == (nx - 1) % BCN_WAVE) {
+#pragma unroll
+          for (int bb = 0; bb < NB; bb++) {
+            const int jj = 1 + ty + NW * bb;
+            if (jj <= ny) {
+              if (tx == 0) dst[jj * sx + 0] = REGS ? pc[REGS ? bb : 0][0] : dst[jj * sx + 1];
+              if (tx == (nx - 1) % BCN_WAVE)
+                dst[jj * sx + nx + 1] = REGS ? pc[REGS ? bb : 0][aE < NA ? aE : 0] : dst[jj * sx + nx];
+            }
+          }
+        }
+        if (ty == 0) {
+#pragma unroll
+          for (int aa = 0; aa < NA; aa++) {
+            const int ii = 1 + tx + BCN_WAVE * aa;
+            if (ii <= nx) dst[0 * sx + ii] = REGS ? pc[0][aa] : dst[1 * sx + ii];
+          }
+        }
+        if (ty == (ny - 1) % NW) {
+          const int bT = (ny - 1) / NW;                 // slot row that holds j == ny
+#pragma unroll
+          for (int aa = 0; aa < NA; aa++) {
+            const int ii = 1 + tx + BCN_WAVE * aa;
+            if (ii <= nx) {
+              real top = 0;
+              if (A.kind == 0) {
+                if constexpr (REGS) {
+#pragma unroll
+                  for (int bb = 0; bb < NB; bb++) if (bb == bT) top = pc[bb][aa];
+                } else {
+                  top = dst[ny * sx + ii];
+                }
+              }
+              dst[(ny + 1) * sx + ii] = top;
+            }
+          }
+        }
+        err = block_sum<real, NT>(loc, red + (itp & 1) * NW);
+        itp++;
+        real* t = src; src = dst; dst = t;
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
+      } while (err > A.tol);
+    } else {
+      // rolled loops; ghosts of the destination buffer are materialised by the edge-cell owners
+      for (int c = tid; c < A.ncell; c += NT) { W0[c] = 0; W1[c] = 0; }
+      for (int j = 1 + ty; j <= ny; j += NW)
+        for (int i = 1 + tx; i <= nx; i += BCN_WAVE) {
+          const int c = j * sx + i;
+          W2[c] = A.cb * ((us[c + 1] - us[c]) * A.rdx + (vs[c + sx] - vs[c]) * A.rdy);
+        }
+      __syncthreads();
+
+      // ---- Jacobi sweeps (rayleigh.py:419-454 / mixing.py:428-463) ----
+      do {
+        real loc = 0;
+        for (int j = 1 + ty; j <= ny; j += NW) {
+          const bool top = (j == ny), bot = (j == 1);
+          const real wrow = real(1) + (bot ? 1 : 0) + ((top && A.kind == 0) ? 1 : 0);
+          for (int i = 1 + tx; i <= nx; i += BCN_WAVE) {
+            const int c = j * sx + i;
+            const real ph = A.cx * (src[c + 1] + src[c - 1]) + A.cy * (src[c + sx] + src[c - sx]) - W2[c];
+            const real d = ph - src[c];
+            const real w = wrow + (i == 1 ? 1 : 0) + (i == nx ? 1 : 0);
+            loc += w * d * d;
+            dst[c] = ph;
+            if (i == 1) dst[c - 1] = ph;
+            if (i == nx) dst[c + 1] = ph;
+            if (bot) dst[c - sx] = ph;
+            if (top) dst[c + sx] = (A.kind == 0) ? ph : real(0);
+          }
+        }
+        err = block_sum<real, NT>(loc, red + (itp & 1) * NW);
+        itp++;
+        real* t = src; src = dst; dst = t;
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
+      } while (err > A.tol);
+    }
     real* phi = src;  // converged field (interior); `dst` is free
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 
@@ -329,8 +429,10 @@ size_t ns2d_generic_lds_bytes(int ncell, size_t esz) {
 
 template <typename real>
 int ns2d_launch_generic(const NS2DArgs<real>& a, int batch, hipStream_t s) {
-  // 16 waves when there is enough work per replica to feed them, else 4
-  if (a.nx * a.ny >= 4096) return launch_step<real, 1024>(a, batch, s);
+  // 16 waves when there is enough work per replica to feed them, else 4 (BCN_GENERIC_NT overrides: experiments)
+  static int force_nt = -1;
+  if (force_nt < 0) { const char* e = getenv("BCN_GENERIC_NT"); force_nt = e ? atoi(e) : 0; }
+  if (force_nt == 1024 || (force_nt == 0 && a.nx * a.ny >= 4096)) return launch_step<real, 1024>(a, batch, s);
   return launch_step<real, 256>(a, batch, s);
 }
 
