@@ -178,6 +178,9 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
       const real wW = (tx == 0) ? real(1) : real(0);                   // i == 1  (slot column 0)
       const real wE = (tx == (nx - 1) % BCN_WAVE) ? real(1) : real(0); // i == nx (slot column aE)
       __syncthreads();
+#ifdef BCN_STAMP
+      unsigned long long gs0 = 0, gs1 = 0, gt = __builtin_amdgcn_s_memtime();
+#endif
       do {
         real loc = 0;
 #pragma unroll
@@ -241,11 +244,20 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
             }
           }
         }
+#ifdef BCN_STAMP
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); gs0 += t_ - gt; gt = t_; __builtin_amdgcn_sched_barrier(0); }
+#endif
         err = block_sum<real, NT>(loc, red + (itp & 1) * NW);
+#ifdef BCN_STAMP
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); gs1 += t_ - gt; gt = t_; __builtin_amdgcn_sched_barrier(0); }
+#endif
         itp++;
         real* t = src; src = dst; dst = t;
         if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
       } while (err > A.tol);
+#ifdef BCN_STAMP
+      if (tid == 0 && A.sweeps) { A.sweeps[(size_t)b * A.ndt_act + it] = itp | ((int)(gs0 / itp / 16) << 12) | ((int)(gs1 / itp / 16) << 22); }
+#endif
     } else {
       // rolled loops; ghosts of the destination buffer are materialised by the edge-cell owners
       for (int c = tid; c < A.ncell; c += NT) { W0[c] = 0; W1[c] = 0; }
@@ -282,7 +294,9 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
       } while (err > A.tol);
     }
     real* phi = src;  // converged field (interior); `dst` is free
+#ifndef BCN_STAMP
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
+#endif
 
     // ---- p += phi incl. ghosts (rayleigh.py:219), corrector (rayleigh.py:460-464) ----
     for (int j = 1 + ty; j <= ny; j += NW)
@@ -326,14 +340,14 @@ __global__ __launch_bounds__(NT) void ns2d_generic_step(NS2DArgs<real> A) {
     {
       const int dmax = nx + ny;
       const int maxlen = nx < ny ? nx : ny;
-      if (LDSW && maxlen <= BCN_WAVE) {
-        // one wave walks all diagonals; LDS operations of one wave complete in issue order
+      if (LDSW && maxlen <= 4 * BCN_WAVE) {
+        // one wave walks all diagonals (up to 4 cells per lane); LDS operations of one wave complete
+        // in issue order, so no workgroup barrier is needed between diagonals
         if (ty == 0) {
           for (int d = 2; d <= dmax; d++) {
             const int i0 = (d - ny > 1) ? d - ny : 1;
             const int i1 = (d - 1 < nx) ? d - 1 : nx;
-            const int i = i0 + tx;
-            if (i <= i1) {
+            for (int i = i0 + tx; i <= i1; i += BCN_WAVE) {
               const int c = (d - i) * sx + i;
               X[c] = X[c] + Y[c] * X[c - 1] + Z[c] * X[c - sx];
             }
