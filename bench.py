@@ -39,7 +39,7 @@ def measured_traffic(kernel_name):
         except Exception:
             continue
         for name, c in d.get("pmc", {}).items():
-            if name.startswith(kernel_name) and "hbm_bytes_per_dispatch" in c:
+            if name.startswith(kernel_name[:9]) and "hbm_bytes_per_dispatch" in c and "reset" not in name:
                 calls = d.get("kernels", {}).get(name, {}).get("calls")
                 n = c["FETCH_SIZE"]["dispatches"]
                 steps = d.get("bench_steps_incl_warmup", 6)
