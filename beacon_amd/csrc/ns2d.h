@@ -58,3 +58,6 @@ size_t ns2d_generic_lds_bytes(int ncell, size_t esz);
 // register-resident CDNA4 path (ns2d_fast.hip); returns BCN_ERR_UNSUPPORTED when the grid has none
 template <typename real> bool ns2d_fast_supported(const NS2DArgs<real>& a);
 template <typename real> int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s);
+// two-rows-per-lane variant for 64 < ny <= 128 (ns2d_fast2.hip), reached through ns2d_launch_fast
+template <typename real> bool ns2d_fast2_supported(const NS2DArgs<real>& a);
+template <typename real> int ns2d_launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s);

@@ -22,6 +22,7 @@
 
 #include <type_traits>
 
+#include "bcn_dpp.h"
 #include "ns2d.h"
 #include "ns2d_device.h"
 
@@ -34,66 +35,7 @@
 
 namespace {
 
-// ---- DPP primitives (verified on gfx950 by scripts/dpp_test.hip) ----------------------------
-template <int CTRL, int RM, int BM, bool BC>
-__device__ __forceinline__ float dpp(float oldv, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv),
-                                                               __builtin_bit_cast(int, v), CTRL, RM, BM, BC));
-}
-template <int CTRL, int RM, int BM, bool BC>
-__device__ __forceinline__ double dpp(double oldv, double v) {
-  const long long o = __builtin_bit_cast(long long, oldv), s = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)s, CTRL, RM, BM, BC);
-  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), CTRL, RM, BM, BC);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-// value of the lane below (row j-1); lane 0 keeps `oldv`
-template <typename real> __device__ __forceinline__ real from_below(real oldv, real v) { return dpp<0x138, 0xf, 0xf, false>(oldv, v); }
-// value of the lane above (row j+1); lane 63 keeps `oldv`
-template <typename real> __device__ __forceinline__ real from_above(real oldv, real v) { return dpp<0x130, 0xf, 0xf, false>(oldv, v); }
-
-// acc + north + south neighbour (values of the lanes above and below, 0 outside the wave) as two
-// fused v_add_f32_dpp.  hipcc fuses the DPP move into the add only for some of the stencil cells, so
-// the pair is spelled out.  hipcc does not model instructions inside an asm statement: it once
-// scheduled the VALU write of `c` directly in front of this statement (VALU write -> DPP read of the
-// same VGPR needs 2 wait states; symptom: replicas with identical inputs diverged), hence the
-// leading s_nop 1.  The second add reads `c` by DPP again and `t` as a plain operand: no hazard.
-__device__ __forceinline__ float add_above_below(float acc, float c) {
-  float t, r;
-  asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %2, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %1, %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-      : "=&v"(t), "=v"(r)
-      : "v"(c), "v"(acc));
-  return r;
-}
-__device__ __forceinline__ double add_above_below(double acc, double c) {
-  return acc + dpp<0x130, 0xf, 0xf, true>(0.0, c) + dpp<0x138, 0xf, 0xf, true>(0.0, c);
-}
-
-template <typename real>
-__device__ __forceinline__ real row16_sum(real s) {  // lane 15 of each 16-lane row: sum of the row
-  s += dpp<0x111, 0xf, 0xf, true>(real(0), s);
-  s += dpp<0x112, 0xf, 0xf, true>(real(0), s);
-  s += dpp<0x114, 0xf, 0xf, true>(real(0), s);
-  s += dpp<0x118, 0xf, 0xf, true>(real(0), s);
-  return s;
-}
-template <typename real>
-__device__ __forceinline__ real wave_sum_lane63(real s) {  // lane 63: sum over the wave
-  s = row16_sum(s);
-  s += dpp<0x142, 0xa, 0xf, false>(real(0), s);
-  s += dpp<0x143, 0xc, 0xf, false>(real(0), s);
-  return s;
-}
-__device__ __forceinline__ float read_lane(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ __forceinline__ double read_lane(double v, int l) {
-  const long long s = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_readlane((int)s, l), hi = __builtin_amdgcn_readlane((int)(s >> 32), l);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
+using namespace bcn_dpp;
 
 template <int NX, int NY, int R>
 struct FastGeom {
@@ -772,10 +714,11 @@ int fast_config(const NS2DArgs<real>& a) {
 }  // namespace
 
 template <typename real>
-bool ns2d_fast_supported(const NS2DArgs<real>& a) { return fast_config<real>(a) != 0; }
+bool ns2d_fast_supported(const NS2DArgs<real>& a) { return fast_config<real>(a) != 0 || ns2d_fast2_supported<real>(a); }
 
 template <typename real>
 int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  if (ns2d_fast2_supported<real>(a)) return ns2d_launch_fast2<real>(a, batch, s);
   switch (fast_config<real>(a)) {
     case 1:
       if constexpr (std::is_same<real, float>::value) return launch_fast<float, 128, 64, BCN_R128, 0>(a, batch, s);

@@ -1,0 +1,481 @@
+// ns2d_fast2.hip -- register-resident action step for grids with 64 < ny <= 128 (mixing 100x100).
+//
+// Same construction as ns2d_fast.hip, with TWO rows per lane: lane l holds rows j = 2l+1 and 2l+2
+// of the R columns i = w*R+1 .. w*R+R owned by wave w.  Consequences:
+//   * a cell has ONE cross-lane y-neighbour (row 2l+1 looks down to lane l-1's upper row, row 2l+2
+//     looks up to lane l+1's lower row), the other one is the thread's own register: one DPP
+//     shift per cell instead of two;
+//   * the lanes above the last row pair are kept at phi = 0, which IS mixing's top Dirichlet
+//     ghost (mixing.py:450-451); a Neumann top (rayleigh) is a per-lane coefficient of the
+//     centre value, as is the Neumann bottom;
+//   * u*, v* are stored in place of u, v in LDS after the predictor (u, v are dead until the
+//     corrector rewrites them), so the Jacobi loop keeps p, rhs and the phi ping-pong in VGPRs:
+//     4 x 2R registers;
+//   * transport: the scalar does not feed back into the flow within a timestep (mixing) or only
+//     through the next predictor (rayleigh), and with 100 rows a diagonal no longer fits one
+//     register per lane, so ONE wave walks the anti-diagonals through LDS (operations of one wave
+//     complete in issue order; up to 2 cells per lane per diagonal).
+// Semantics and citations: ns2d_generic.hip.  Plain launch, one workgroup per replica.
+#include <type_traits>
+
+#include "bcn_dpp.h"
+#include "ns2d.h"
+#include "ns2d_device.h"
+
+namespace {
+
+using namespace bcn_dpp;
+
+template <int NX, int NY, int R>
+struct Fast2Geom {
+  static_assert(NX % R == 0, "strip width must divide nx");
+  static_assert(NY % 2 == 0 && NY <= 128, "two rows per lane");
+  static constexpr int NW = NX / R;
+  static_assert(NW <= 16, "at most 16 waves");
+  static constexpr int NT = NW * 64;
+  static constexpr int LH = NY / 2;        // active lanes
+  static constexpr int SY = NY + 2;
+  static constexpr int SX = NX + 2;
+  static constexpr int SZ = SX * SY;
+  // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 32 | sact 64 | red 32 | U V S
+  static constexpr int EXCH = 2 * NW * 4 * 64;
+  static constexpr size_t lds_elems() { return (size_t)EXCH + 128 + 3 * (size_t)SZ; }
+};
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
+  using G = Fast2Geom<NX, NY, R>;
+  constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, LH = G::LH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  real* exch = reinterpret_cast<real*>(smem);
+  real* errp = exch + G::EXCH;   // [2][16]
+  real* sact = errp + 32;        // [64]
+  real* red = sact + 64;         // [32]
+  real* Ul = red + 32;
+  real* Vl = Ul + SZ;
+  real* Tl = Vl + SZ;
+
+  const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool active = lane < LH;
+  const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
+  const int j0 = 2 * la + 1;                 // rows j0 (a = 0) and j0 + 1 (a = 1)
+  const int i0 = w * R + 1;
+  const size_t off = (size_t)b * A.ncell;
+  real* __restrict__ gu = A.u + off;
+  real* __restrict__ gv = A.v + off;
+  real* __restrict__ gp = A.p + off;
+  real* __restrict__ gS = A.S + off;
+  auto ex = [&](int buf, int wave, int side, int a) -> real* {
+    return exch + (((buf * NW + wave) * 2 + side) * 2 + a) * 64;
+  };
+
+  // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
+  for (int c = tid; c < SX * SY; c += NT) {
+    const int jj = c / SX, ii = c - jj * SX;
+    Ul[ii * SY + jj] = gu[c];
+    Vl[ii * SY + jj] = gv[c];
+    Tl[ii * SY + jj] = gS[c];
+  }
+  if (tid < 32) errp[tid] = 0;
+  real p[2][R];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int k = 0; k < R; k++) p[a][k] = active ? gp[(j0 + a) * SX + i0 + k] : real(0);
+
+  // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----------
+  real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
+  if (KIND == 0) {
+    const int n = A.n_sgts;
+    const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
+    real mean = 0;
+    for (int k = 0; k < n; k++) mean += src[k];
+    mean /= (real)n;
+    real m = 1;
+    for (int k = 0; k < n; k++) {
+      real t = bcn_abs(src[k] - mean) / A.C;
+      m = t > m ? t : m;
+    }
+    real mine = (tid < n) ? (src[tid] - mean) / m : real(0);
+    __syncthreads();
+    if (tid < n) {
+      sact[tid] = mine;
+      A.a_last[(size_t)b * n + tid] = mine;
+      if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
+    }
+  } else {
+    const int act = A.iactions ? A.iactions[b] : A.ia_last[b];
+    __syncthreads();
+    if (tid == 0) A.ia_last[b] = act;
+    if (act == 0) { u_b = A.u_max; u_t = -A.u_max; }
+    if (act == 1) { u_b = -A.u_max; u_t = A.u_max; }
+    if (act == 2) { v_r = A.u_max; v_l = -A.u_max; }
+    if (act == 3) { v_r = -A.u_max; v_l = A.u_max; }
+  }
+  __syncthreads();
+
+  const real dt = A.dt, rdx = A.rdx, rdy = A.rdy, rdx2 = A.rdx2, rdy2 = A.rdy2;
+  const real cx = A.cx, cy = A.cy;
+  const real actf = active ? real(1) : real(0);
+  // y-ghost coefficients of the centre value: bottom row (lane 0, a = 0) always Neumann; top row
+  // (last active lane, a = 1) Neumann for rayleigh, Dirichlet 0 for mixing
+  const real cB0 = (lane == 0) ? cy : real(0);
+  const real cB1 = (lane == LH - 1 && KIND == 0) ? cy : real(0);
+  // error weights of this lane's two rows (ghosts copy their interior neighbour)
+  const real wl0 = active ? real(1) + (lane == 0 ? 1 : 0) : real(0);
+  const real wl1 = active ? real(1) + ((lane == LH - 1 && KIND == 0) ? 1 : 0) : real(0);
+  const real fW = (active && w == 0) ? real(1) : real(0);
+  const real fE = (active && w == NW - 1) ? real(1) : real(0);
+  const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
+
+  int status = 0;
+  int xb = 0;
+#ifdef BCN_STAMP
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tl = __builtin_amdgcn_s_memtime();
+#define BCN_PH(x) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); seg[x] += t__ - tl; tl = t__; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BCN_PH(x)
+#endif
+  for (int it = 0; it < A.ndt_act && status == 0; it++) {
+    // ---- boundary conditions on the LDS fields (rayleigh.py:180-202 / mixing.py:153-171) ------
+    for (int jj = 1 + tid; jj <= NY; jj += NT) {
+      Ul[1 * SY + jj] = 0;
+      Ul[(NX + 1) * SY + jj] = 0;
+      if (jj >= 2) {
+        Vl[0 * SY + jj] = 2 * v_l - Vl[1 * SY + jj];
+        Vl[(NX + 1) * SY + jj] = 2 * v_r - Vl[NX * SY + jj];
+      }
+      Tl[0 * SY + jj] = Tl[1 * SY + jj];
+      Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
+    }
+    for (int ii = 1 + tid; ii <= NX + 1; ii += NT) {
+      const bool wall = (ii == 1) || (ii == NX + 1);
+      const real utop = wall ? real(0) : Ul[ii * SY + NY];
+      const real ubot = wall ? real(0) : Ul[ii * SY + 1];
+      Ul[ii * SY + NY + 1] = 2 * u_t - utop;
+      Ul[ii * SY + 0] = 2 * u_b - ubot;
+      if (ii <= NX) {
+        Vl[ii * SY + NY + 1] = 0;
+        Vl[ii * SY + 1] = 0;
+        if (KIND == 0) {
+          Tl[ii * SY + NY + 1] = 2 * A.Tc - Tl[ii * SY + NY];
+          const int k = (ii - 1) / A.nx_sgts;
+          if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
+        } else {
+          Tl[ii * SY + NY + 1] = Tl[ii * SY + NY];
+          Tl[ii * SY + 0] = Tl[ii * SY + 1];
+        }
+      }
+    }
+    ex(xb, w, 1, 0)[lane] = p[0][R - 1];
+    ex(xb, w, 1, 1)[lane] = p[1][R - 1];
+    __syncthreads();
+    BCN_PH(0)
+
+    // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* (registers, then LDS) ---
+    real us[2][R], vs[2][R];
+    {
+      const real pWh0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0);
+      const real pWh1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
+      xb ^= 1;
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        __builtin_amdgcn_sched_barrier(0);   // finish one row before loading the next: register pressure
+        const int j = j0 + a;
+        real ur[R + 2], uS[R + 1], uN[R], vr[R + 2], vN[R + 1], vS[R];
+#pragma unroll
+        for (int k = 0; k < R + 2; k++) { ur[k] = Ul[(i0 - 1 + k) * SY + j]; vr[k] = Vl[(i0 - 1 + k) * SY + j]; }
+#pragma unroll
+        for (int k = 0; k < R + 1; k++) { uS[k] = Ul[(i0 + k) * SY + j - 1]; vN[k] = Vl[(i0 - 1 + k) * SY + j + 1]; }
+#pragma unroll
+        for (int k = 0; k < R; k++) { uN[k] = Ul[(i0 + k) * SY + j + 1]; vS[k] = Vl[(i0 + k) * SY + j - 1]; }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const int i = i0 + k;
+          const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
+          const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
+          const real pc = p[a][k];
+          const real pW = (k > 0) ? p[a][k > 0 ? k - 1 : 0] : (a == 0 ? pWh0 : pWh1);
+          // south neighbour of the lower row lives in the lane below (its upper row)
+          const real pS = (a == 0) ? from_below(p[1][k], p[1][k]) : p[0][k];
+          {
+            real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+            real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
+            real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
+            real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
+            real pres = (pc - pW) * rdx;
+            us[a][k] = (i >= 2) ? uc + dt * (diff - conv - pres) : real(0);
+          }
+          {
+            real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+            real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
+            real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
+            real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
+            real pres = (pc - pS) * rdy;
+            const real buoy = (KIND == 0) ? Tl[i * SY + j] : real(0);
+            vs[a][k] = (j >= 2) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // every read of the old u, v is done: u*, v* take their place
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          Ul[(i0 + k) * SY + j0 + a] = us[a][k];
+          Vl[(i0 + k) * SY + j0 + a] = vs[a][k];
+        }
+    }
+    __syncthreads();
+
+    // ---- Poisson rhs from u*, v* in LDS (u*[1,.] = u*[nx+1,.] = v*[.,1] = v*[.,ny+1] = 0 are the
+    //      wall values the BC pass left there) ------------------------------------------------
+    real nb[2][R];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const int j = j0 + a;
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const int c = (i0 + k) * SY + j;
+        const real div = (Ul[c + SY] - Ul[c]) * rdx + (Vl[c + 1] - Vl[c]) * rdy;
+        nb[a][k] = active ? -A.cb * div : real(0);
+      }
+    }
+
+    BCN_PH(1)
+    // ---- Jacobi sweeps: one barrier per sweep, phi ping-pong in registers ---------------------
+    real phA[2][R], phB[2][R];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int k = 0; k < R; k++) phA[a][k] = 0;
+    real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
+    real eL = 0, hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
+    int itp = 0;
+    bool finalB = false;
+    // lower row (a = 0): south = lane below's upper row (DPP), north = own upper row;
+    // upper row (a = 1): south = own lower row, north = lane above's lower row (DPP)
+#define BCN_CELL(DST, SRC, K, EV, WV)                                                                \
+    {                                                                                                \
+      const real c0 = SRC[0][K], c1 = SRC[1][K];                                                     \
+      const real s0 = dpp<0x138, 0xf, 0xf, true>(real(0), c1);   /* lane below's upper row */        \
+      const real n1 = dpp<0x130, 0xf, 0xf, true>(real(0), c0);   /* lane above's lower row */        \
+      real ph0, ph1;                                                                                 \
+      if (EQ) {                                                                                      \
+        ph0 = cx * ((EV##0 + WV##0) + (s0 + c1)) + (cB0 * c0 + nb[0][K]);                            \
+        ph1 = cx * ((EV##1 + WV##1) + (c0 + n1)) + (cB1 * c1 + nb[1][K]);                            \
+      } else {                                                                                       \
+        ph0 = cx * (EV##0 + WV##0) + (cy * (s0 + c1) + (cB0 * c0 + nb[0][K]));                       \
+        ph1 = cx * (EV##1 + WV##1) + (cy * (c0 + n1) + (cB1 * c1 + nb[1][K]));                       \
+      }                                                                                              \
+      ph0 *= actf;                                                                                   \
+      ph1 *= actf;                                                                                   \
+      const real d0 = ph0 - c0, d1 = ph1 - c1;                                                       \
+      acc0 += d0 * d0;                                                                               \
+      acc1 += d1 * d1;                                                                               \
+      if (K == 0) { dW0 = d0 * d0; dW1 = d1 * d1; }                                                  \
+      if (K == R - 1) { dE0 = d0 * d0; dE1 = d1 * d1; }                                              \
+      DST[0][K] = ph0;                                                                               \
+      DST[1][K] = ph1;                                                                               \
+    }
+#define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                                \
+    {                                                                                                \
+      real acc0 = 0, acc1 = 0, dW0 = 0, dW1 = 0, dE0 = 0, dE1 = 0;                                   \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                            \
+        const real e0 = SRC[0][k + 1], e1 = SRC[1][k + 1], w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];  \
+        BCN_CELL(DST, SRC, k, e, w)                                                                  \
+      }                                                                                              \
+      if (itp > 0) {                                                                                 \
+        const real err = read_lane(row16_sum<real>(eL), 15);                                         \
+        hW0 = (w > 0) ? hW0r : SRC[0][0];                                                            \
+        hW1 = (w > 0) ? hW1r : SRC[1][0];                                                            \
+        hE0 = (w < NW - 1) ? hE0r : SRC[0][R - 1];                                                   \
+        hE1 = (w < NW - 1) ? hE1r : SRC[1][R - 1];                                                   \
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }                     \
+        if (!(err > A.tol)) { finalB = SRC_IS_B; break; }                                            \
+      }                                                                                              \
+      {                                                                                              \
+        const real e0 = SRC[0][1], e1 = SRC[1][1], w0 = hW0, w1 = hW1;                               \
+        BCN_CELL(DST, SRC, 0, e, w)                                                                  \
+      }                                                                                              \
+      {                                                                                              \
+        const real e0 = hE0, e1 = hE1, w0 = SRC[0][R - 2], w1 = SRC[1][R - 2];                       \
+        BCN_CELL(DST, SRC, R - 1, e, w)                                                              \
+      }                                                                                              \
+      const real part = wl0 * acc0 + wl1 * acc1 + fW * (wl0 * dW0 + wl1 * dW1) + fE * (wl0 * dE0 + wl1 * dE1); \
+      const real tot63 = wave_sum_lane63<real>(part);                                                \
+      ex(xb, w, 0, 0)[lane] = DST[0][0];                                                             \
+      ex(xb, w, 0, 1)[lane] = DST[1][0];                                                             \
+      ex(xb, w, 1, 0)[lane] = DST[0][R - 1];                                                         \
+      ex(xb, w, 1, 1)[lane] = DST[1][R - 1];                                                         \
+      if (lane == 63) errp[xb * 16 + w] = tot63;                                                     \
+      __syncthreads();                                                                               \
+      itp++;                                                                                         \
+      eL = errp[xb * 16 + (lane & 15)];                                                              \
+      hW0r = ex(xb, wm, 1, 0)[lane];                                                                 \
+      hW1r = ex(xb, wm, 1, 1)[lane];                                                                 \
+      hE0r = ex(xb, wp, 0, 0)[lane];                                                                 \
+      hE1r = ex(xb, wp, 0, 1)[lane];                                                                 \
+      xb ^= 1;                                                                                       \
+    }
+    for (;;) {
+      BCN_SWEEP(phA, phB, false)
+      BCN_SWEEP(phB, phA, true)
+    }
+#undef BCN_SWEEP
+#undef BCN_CELL
+    if (finalB) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < R; k++) phA[a][k] = phB[a][k];
+    }
+    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
+
+    BCN_PH(2)
+    // ---- p += phi, corrector: u = u* - dt dphi/dx, v = v* - dt dphi/dy (in place in LDS) -------
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const int j = j0 + a;
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const int i = i0 + k;
+        const real ph = phA[a][k];
+        const real pw = (k > 0) ? phA[a][k > 0 ? k - 1 : 0] : (a == 0 ? hW0 : hW1);
+        const real ps = (a == 0) ? from_below(phA[1][k], phA[1][k]) : phA[0][k];
+        p[a][k] += ph;
+        if (active) {
+          const int c = i * SY + j;
+          if (i >= 2) Ul[c] = Ul[c] - dt * (ph - pw) * rdx;
+          if (j >= 2) Vl[c] = Vl[c] - dt * (ph - ps) * rdy;
+        }
+      }
+    }
+    __syncthreads();
+
+    BCN_PH(3)
+    // ---- transport: explicit part of every cell, then the ordered part by one wave ------------
+    {
+      real Ac[2][R];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const int c = (i0 + k) * SY + j0 + a;
+          const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
+          const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
+          const real expl = A.ksc * ((TE - 2 * T0) * rdx2 + (TN - 2 * T0) * rdy2) -
+                            (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
+                            (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
+          Ac[a][k] = T0 + dt * expl;
+        }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int k = 0; k < R; k++) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
+      }
+    }
+    __syncthreads();
+    BCN_PH(4)
+    if (w == 0) {
+      const real c0x = dt * A.ksc * rdx2, c1x = real(0.5) * dt * rdx;
+      const real c0y = dt * A.ksc * rdy2, c1y = real(0.5) * dt * rdy;
+      for (int d = 2; d <= NX + NY; d++) {
+        const int ilo = (d - NY > 1) ? d - NY : 1;
+        const int ihi = (d - 1 < NX) ? d - 1 : NX;
+        for (int i = ilo + lane; i <= ihi; i += 64) {
+          const int c = i * SY + (d - i);
+          const real aw = c0x + c1x * Ul[c], as = c0y + c1y * Vl[c];
+          Tl[c] = Tl[c] + aw * Tl[c - SY] + as * Tl[c - 1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    BCN_PH(5)
+  }
+
+  // ---- store: LDS [i][j] -> HBM [j][i]; p and its ghosts -------------------------------------
+  for (int c = tid; c < SX * SY; c += NT) {
+    const int jj = c / SX, ii = c - jj * SX;
+    gu[c] = Ul[ii * SY + jj];
+    gv[c] = Vl[ii * SY + jj];
+    gS[c] = Tl[ii * SY + jj];
+  }
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        const int i = i0 + k, j = j0 + a, c = j * SX + i;
+        const real dp = p[a][k] - gp[c];
+        if (i == 1) gp[c - 1] += dp;
+        if (i == NX) gp[c + 1] += dp;
+        if (j == 1) gp[c - SX] += dp;
+        if (j == NY && KIND == 0) gp[c + SX] += dp;
+        gp[c] = p[a][k];
+      }
+  }
+  __syncthreads();
+  ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
+#ifdef BCN_STAMP   // diagnostic build only: cycles per timestep of each phase over the first obs entries
+  __syncthreads();
+  if (tid == 0 && A.obs_out)
+    for (int q = 0; q < 6; q++) A.obs_out[(size_t)b * A.n_obs + q] = (real)seg[q] / (real)A.ndt_act;
+#endif
+}
+
+template <typename real, int NX, int NY, int R, int KIND>
+int launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  using G = Fast2Geom<NX, NY, R>;
+  const size_t lds = G::lds_elems() * sizeof(real);
+  NS2DArgs<real> c = a;
+  if (!c.sweeps) c.sweeps = c.sweeps_int;
+  if (a.cx == a.cy) {
+    auto k = ns2d_fast2_step<real, NX, NY, R, KIND, true>;
+    static bool set = false;
+    if (!set) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  } else {
+    auto k = ns2d_fast2_step<real, NX, NY, R, KIND, false>;
+    static bool set = false;
+    if (!set) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  }
+  BCN_HIP(hipGetLastError());
+  return BCN_OK;
+}
+
+}  // namespace
+
+template <typename real>
+bool ns2d_fast2_supported(const NS2DArgs<real>& a) {
+  return sizeof(real) == 4 && a.nx == 100 && a.ny == 100 && (a.kind == 1 || a.n_sgts <= 64);
+}
+
+template <typename real>
+int ns2d_launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  if constexpr (std::is_same<real, float>::value) {
+    if (a.nx == 100 && a.ny == 100) {
+      if (a.kind == 1) return launch_fast2<float, 100, 100, 10, 1>(a, batch, s);
+      return launch_fast2<float, 100, 100, 10, 0>(a, batch, s);
+    }
+  }
+  bcn_set_error("no two-rows-per-lane kernel for this grid");
+  return BCN_ERR_UNSUPPORTED;
+}
+
+template bool ns2d_fast2_supported<float>(const NS2DArgs<float>&);
+template bool ns2d_fast2_supported<double>(const NS2DArgs<double>&);
+template int ns2d_launch_fast2<float>(const NS2DArgs<float>&, int, hipStream_t);
+template int ns2d_launch_fast2<double>(const NS2DArgs<double>&, int, hipStream_t);
