@@ -41,6 +41,20 @@ __device__ __forceinline__ double add_above_below(double acc, double c) {
   return acc + dpp<0x130, 0xf, 0xf, true>(0.0, c) + dpp<0x138, 0xf, 0xf, true>(0.0, c);
 }
 
+// Two-rows-per-lane stencils (ns2d_fast2.hip): lo + (hi of the lane below) and hi + (lo of the lane
+// above), 0 outside the wave, as fused v_add_f32_dpp (same s_nop rule as above).
+__device__ __forceinline__ void add_pair_neighbours(float lo, float hi, float& s_plus_hi, float& lo_plus_n) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(s_plus_hi), "=&v"(lo_plus_n)
+      : "v"(lo), "v"(hi));
+}
+__device__ __forceinline__ void add_pair_neighbours(double lo, double hi, double& s_plus_hi, double& lo_plus_n) {
+  s_plus_hi = dpp<0x138, 0xf, 0xf, true>(0.0, hi) + hi;
+  lo_plus_n = lo + dpp<0x130, 0xf, 0xf, true>(0.0, lo);
+}
+
 template <typename real>
 __device__ __forceinline__ real row16_sum(real s) {  // lane 15 of each 16-lane row: sum of the row
   s += dpp<0x111, 0xf, 0xf, true>(real(0), s);

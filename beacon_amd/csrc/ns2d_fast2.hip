@@ -1,7 +1,9 @@
 // ns2d_fast2.hip -- register-resident action step for grids with 64 < ny <= 128 (mixing 100x100).
 //
 // Same construction as ns2d_fast.hip, with TWO rows per lane: lane l holds rows j = 2l+1 and 2l+2
-// of the R columns i = w*R+1 .. w*R+R owned by wave w.  Consequences:
+// of the columns i = w*R+1 .. owned by wave w (R columns; the last wave takes the remainder RL, its
+// code is a second instantiation of the same body selected by a wave-uniform branch, so 100 columns
+// run as 7 x 13 + 9 on 8 waves = 512 threads = 2 waves per SIMD with 256 VGPRs each).  Consequences:
 //   * a cell has ONE cross-lane y-neighbour (row 2l+1 looks down to lane l-1's upper row, row 2l+2
 //     looks up to lane l+1's lower row), the other one is the thread's own register: one DPP
 //     shift per cell instead of two;
@@ -11,10 +13,9 @@
 //   * u*, v* are stored in place of u, v in LDS after the predictor (u, v are dead until the
 //     corrector rewrites them), so the Jacobi loop keeps p, rhs and the phi ping-pong in VGPRs:
 //     4 x 2R registers;
-//   * transport: the scalar does not feed back into the flow within a timestep (mixing) or only
-//     through the next predictor (rayleigh), and with 100 rows a diagonal no longer fits one
-//     register per lane, so ONE wave walks the anti-diagonals through LDS (operations of one wave
-//     complete in issue order; up to 2 cells per lane per diagonal).
+//   * transport: ONE wave walks the skewed wavefront "lane l works on column t - l" with both of
+//     its rows per step; the west values stay in registers, the south value of the lower row comes
+//     from the lane below by DPP (transport_chain2).
 // Semantics and citations: ns2d_generic.hip.  Plain launch, one workgroup per replica.
 #include <type_traits>
 
@@ -28,10 +29,10 @@ using namespace bcn_dpp;
 
 template <int NX, int NY, int R>
 struct Fast2Geom {
-  static_assert(NX % R == 0, "strip width must divide nx");
   static_assert(NY % 2 == 0 && NY <= 128, "two rows per lane");
-  static constexpr int NW = NX / R;
-  static_assert(NW <= 16, "at most 16 waves");
+  static constexpr int NW = (NX + R - 1) / R;
+  static constexpr int RL = NX - (NW - 1) * R;   // columns of the last wave
+  static_assert(NW <= 16 && RL >= 3 && RL <= R, "at most 16 waves, at least 3 columns each");
   static constexpr int NT = NW * 64;
   static constexpr int LH = NY / 2;        // active lanes
   static constexpr int SY = NY + 2;
@@ -42,11 +43,57 @@ struct Fast2Geom {
   static constexpr size_t lds_elems() { return (size_t)EXCH + 128 + 3 * (size_t)SZ; }
 };
 
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
-__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
+// Ordered part of the transport step by ONE wave (out of line, see ns2d_fast.hip).  At step t lane l
+// works on column i = t - l + 1, rows 2l+1 and 2l+2: S' = A + aW S'(i-1,j) + aS S'(i,j-1) with the
+// west values in registers, the south value of the lower row from the lane below (its upper row of
+// the previous step) and the explicit part A, u, v prefetched PD steps ahead from LDS.  Lanes outside
+// the domain compute on clamped addresses and write to `dummy`.
+template <typename real, int NX, int NY>
+__device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real* Ul, const real* Vl, real* dummy,
+                                                           real c0x, real c1x, real c0y, real c1y) {
+  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = NY / 2, PD = 4;
+  constexpr int NSTEP = NX + LH - 1;
+  const int lane = threadIdx.x & 63;
+  const bool active = lane < LH;
+  const int la = active ? lane : LH - 1;
+  const int cb = (1 - la) * SY + 2 * la + 1;     // index of (i, 2l+1) at step t: cb + t*SY
+  auto at = [&](int t) { int x = cb + t * SY; x = x < 1 ? 1 : x; return x > SZ - 2 ? SZ - 2 : x; };
+  real a0[PD], a1[PD], u0[PD], u1[PD], v0[PD], v1[PD], g[PD];
+#pragma unroll
+  for (int q = 0; q < PD; q++) {
+    const int x = at(q);
+    a0[q] = Tl[x]; a1[q] = Tl[x + 1]; g[q] = Tl[x - 1];
+    u0[q] = Ul[x]; u1[q] = Ul[x + 1];
+    v0[q] = Vl[x]; v1[q] = Vl[x + 1];
+  }
+  real tp0 = Tl[2 * la + 1], tp1 = Tl[2 * la + 2];   // west ghosts (column 0)
+  for (int t0 = 0; t0 < NSTEP; t0 += PD) {
+#pragma unroll
+    for (int q = 0; q < PD; q++) {
+      const int t = t0 + q;
+      const real s = from_below(g[q], tp1);          // lane 0: the south ghost T[i][0]
+      const real aw0 = c0x + c1x * u0[q], as0 = c0y + c1y * v0[q];
+      const real aw1 = c0x + c1x * u1[q], as1 = c0y + c1y * v1[q];
+      const real tn0 = a0[q] + aw0 * tp0 + as0 * s;
+      const real tn1 = a1[q] + aw1 * tp1 + as1 * tn0;
+      const bool ok = active && lane <= t && lane > t - NX;
+      tp0 = ok ? tn0 : tp0;
+      tp1 = ok ? tn1 : tp1;
+      real* dst = ok ? Tl + (cb + t * SY) : dummy;
+      dst[0] = tn0;
+      dst[1] = tn1;
+      const int x = at(t + PD);
+      a0[q] = Tl[x]; a1[q] = Tl[x + 1]; g[q] = Tl[x - 1];
+      u0[q] = Ul[x]; u1[q] = Ul[x + 1];
+      v0[q] = Vl[x]; v1[q] = Vl[x + 1];
+    }
+  }
+}
+
+template <typename real, int NX, int NY, int R, int RW, int KIND, bool EQ>
+__device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, const int w) {
   using G = Fast2Geom<NX, NY, R>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, LH = G::LH;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   real* exch = reinterpret_cast<real*>(smem);
   real* errp = exch + G::EXCH;   // [2][16]
   real* sact = errp + 32;        // [64]
@@ -57,7 +104,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 
   const int b = blockIdx.x;
   if (A.mask && !A.mask[b]) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const bool active = lane < LH;
   const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
   const int j0 = 2 * la + 1;                 // rows j0 (a = 0) and j0 + 1 (a = 1)
@@ -79,11 +126,11 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
     Tl[ii * SY + jj] = gS[c];
   }
   if (tid < 32) errp[tid] = 0;
-  real p[2][R];
+  real p[2][RW];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int k = 0; k < R; k++) p[a][k] = active ? gp[(j0 + a) * SX + i0 + k] : real(0);
+    for (int k = 0; k < RW; k++) p[a][k] = active ? gp[(j0 + a) * SX + i0 + k] : real(0);
 
   // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----------
   real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
@@ -118,7 +165,8 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 
   const real dt = A.dt, rdx = A.rdx, rdy = A.rdy, rdx2 = A.rdx2, rdy2 = A.rdy2;
   const real cx = A.cx, cy = A.cy;
-  const real actf = active ? real(1) : real(0);
+  // lanes past the top row pair keep phi = 0: zero coefficients and zero rhs
+  const real cxl = active ? cx : real(0), cyl = active ? cy : real(0);
   // y-ghost coefficients of the centre value: bottom row (lane 0, a = 0) always Neumann; top row
   // (last active lane, a = 1) Neumann for rayleigh, Dirichlet 0 for mixing
   const real cB0 = (lane == 0) ? cy : real(0);
@@ -170,13 +218,13 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
         }
       }
     }
-    ex(xb, w, 1, 0)[lane] = p[0][R - 1];
-    ex(xb, w, 1, 1)[lane] = p[1][R - 1];
+    ex(xb, w, 1, 0)[lane] = p[0][RW - 1];
+    ex(xb, w, 1, 1)[lane] = p[1][RW - 1];
     __syncthreads();
     BCN_PH(0)
 
     // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* (registers, then LDS) ---
-    real us[2][R], vs[2][R];
+    real us[2][RW], vs[2][RW];
     {
       const real pWh0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0);
       const real pWh1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
@@ -185,15 +233,15 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
       for (int a = 0; a < 2; a++) {
         __builtin_amdgcn_sched_barrier(0);   // finish one row before loading the next: register pressure
         const int j = j0 + a;
-        real ur[R + 2], uS[R + 1], uN[R], vr[R + 2], vN[R + 1], vS[R];
+        real ur[RW + 2], uS[RW + 1], uN[RW], vr[RW + 2], vN[RW + 1], vS[RW];
 #pragma unroll
-        for (int k = 0; k < R + 2; k++) { ur[k] = Ul[(i0 - 1 + k) * SY + j]; vr[k] = Vl[(i0 - 1 + k) * SY + j]; }
+        for (int k = 0; k < RW + 2; k++) { ur[k] = Ul[(i0 - 1 + k) * SY + j]; vr[k] = Vl[(i0 - 1 + k) * SY + j]; }
 #pragma unroll
-        for (int k = 0; k < R + 1; k++) { uS[k] = Ul[(i0 + k) * SY + j - 1]; vN[k] = Vl[(i0 - 1 + k) * SY + j + 1]; }
+        for (int k = 0; k < RW + 1; k++) { uS[k] = Ul[(i0 + k) * SY + j - 1]; vN[k] = Vl[(i0 - 1 + k) * SY + j + 1]; }
 #pragma unroll
-        for (int k = 0; k < R; k++) { uN[k] = Ul[(i0 + k) * SY + j + 1]; vS[k] = Vl[(i0 + k) * SY + j - 1]; }
+        for (int k = 0; k < RW; k++) { uN[k] = Ul[(i0 + k) * SY + j + 1]; vS[k] = Vl[(i0 + k) * SY + j - 1]; }
 #pragma unroll
-        for (int k = 0; k < R; k++) {
+        for (int k = 0; k < RW; k++) {
           const int i = i0 + k;
           const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
           const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
@@ -228,7 +276,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int k = 0; k < R; k++) {
+        for (int k = 0; k < RW; k++) {
           Ul[(i0 + k) * SY + j0 + a] = us[a][k];
           Vl[(i0 + k) * SY + j0 + a] = vs[a][k];
         }
@@ -237,12 +285,12 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 
     // ---- Poisson rhs from u*, v* in LDS (u*[1,.] = u*[nx+1,.] = v*[.,1] = v*[.,ny+1] = 0 are the
     //      wall values the BC pass left there) ------------------------------------------------
-    real nb[2][R];
+    real nb[2][RW];
 #pragma unroll
     for (int a = 0; a < 2; a++) {
       const int j = j0 + a;
 #pragma unroll
-      for (int k = 0; k < R; k++) {
+      for (int k = 0; k < RW; k++) {
         const int c = (i0 + k) * SY + j;
         const real div = (Ul[c + SY] - Ul[c]) * rdx + (Vl[c + 1] - Vl[c]) * rdy;
         nb[a][k] = active ? -A.cb * div : real(0);
@@ -251,11 +299,11 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 
     BCN_PH(1)
     // ---- Jacobi sweeps: one barrier per sweep, phi ping-pong in registers ---------------------
-    real phA[2][R], phB[2][R];
+    real phA[2][RW], phB[2][RW];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int k = 0; k < R; k++) phA[a][k] = 0;
+      for (int k = 0; k < RW; k++) phA[a][k] = 0;
     real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
     real eL = 0, hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
     int itp = 0;
@@ -265,30 +313,28 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 #define BCN_CELL(DST, SRC, K, EV, WV)                                                                \
     {                                                                                                \
       const real c0 = SRC[0][K], c1 = SRC[1][K];                                                     \
-      const real s0 = dpp<0x138, 0xf, 0xf, true>(real(0), c1);   /* lane below's upper row */        \
-      const real n1 = dpp<0x130, 0xf, 0xf, true>(real(0), c0);   /* lane above's lower row */        \
+      real sn0, sn1;   /* south + north of the lower / upper row */                                  \
+      add_pair_neighbours(c0, c1, sn0, sn1);                                                         \
       real ph0, ph1;                                                                                 \
       if (EQ) {                                                                                      \
-        ph0 = cx * ((EV##0 + WV##0) + (s0 + c1)) + (cB0 * c0 + nb[0][K]);                            \
-        ph1 = cx * ((EV##1 + WV##1) + (c0 + n1)) + (cB1 * c1 + nb[1][K]);                            \
+        ph0 = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + nb[0][K]);                                 \
+        ph1 = cxl * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                                 \
       } else {                                                                                       \
-        ph0 = cx * (EV##0 + WV##0) + (cy * (s0 + c1) + (cB0 * c0 + nb[0][K]));                       \
-        ph1 = cx * (EV##1 + WV##1) + (cy * (c0 + n1) + (cB1 * c1 + nb[1][K]));                       \
+        ph0 = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + nb[0][K]));                           \
+        ph1 = cxl * (EV##1 + WV##1) + (cyl * sn1 + (cB1 * c1 + nb[1][K]));                           \
       }                                                                                              \
-      ph0 *= actf;                                                                                   \
-      ph1 *= actf;                                                                                   \
       const real d0 = ph0 - c0, d1 = ph1 - c1;                                                       \
       acc0 += d0 * d0;                                                                               \
       acc1 += d1 * d1;                                                                               \
       if (K == 0) { dW0 = d0 * d0; dW1 = d1 * d1; }                                                  \
-      if (K == R - 1) { dE0 = d0 * d0; dE1 = d1 * d1; }                                              \
+      if (K == RW - 1) { dE0 = d0 * d0; dE1 = d1 * d1; }                                              \
       DST[0][K] = ph0;                                                                               \
       DST[1][K] = ph1;                                                                               \
     }
 #define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                                \
     {                                                                                                \
       real acc0 = 0, acc1 = 0, dW0 = 0, dW1 = 0, dE0 = 0, dE1 = 0;                                   \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                            \
+      _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
         const real e0 = SRC[0][k + 1], e1 = SRC[1][k + 1], w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];  \
         BCN_CELL(DST, SRC, k, e, w)                                                                  \
       }                                                                                              \
@@ -296,8 +342,8 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
         const real err = read_lane(row16_sum<real>(eL), 15);                                         \
         hW0 = (w > 0) ? hW0r : SRC[0][0];                                                            \
         hW1 = (w > 0) ? hW1r : SRC[1][0];                                                            \
-        hE0 = (w < NW - 1) ? hE0r : SRC[0][R - 1];                                                   \
-        hE1 = (w < NW - 1) ? hE1r : SRC[1][R - 1];                                                   \
+        hE0 = (w < NW - 1) ? hE0r : SRC[0][RW - 1];                                                   \
+        hE1 = (w < NW - 1) ? hE1r : SRC[1][RW - 1];                                                   \
         if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }                     \
         if (!(err > A.tol)) { finalB = SRC_IS_B; break; }                                            \
       }                                                                                              \
@@ -306,15 +352,15 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
         BCN_CELL(DST, SRC, 0, e, w)                                                                  \
       }                                                                                              \
       {                                                                                              \
-        const real e0 = hE0, e1 = hE1, w0 = SRC[0][R - 2], w1 = SRC[1][R - 2];                       \
-        BCN_CELL(DST, SRC, R - 1, e, w)                                                              \
+        const real e0 = hE0, e1 = hE1, w0 = SRC[0][RW - 2], w1 = SRC[1][RW - 2];                       \
+        BCN_CELL(DST, SRC, RW - 1, e, w)                                                              \
       }                                                                                              \
       const real part = wl0 * acc0 + wl1 * acc1 + fW * (wl0 * dW0 + wl1 * dW1) + fE * (wl0 * dE0 + wl1 * dE1); \
       const real tot63 = wave_sum_lane63<real>(part);                                                \
       ex(xb, w, 0, 0)[lane] = DST[0][0];                                                             \
       ex(xb, w, 0, 1)[lane] = DST[1][0];                                                             \
-      ex(xb, w, 1, 0)[lane] = DST[0][R - 1];                                                         \
-      ex(xb, w, 1, 1)[lane] = DST[1][R - 1];                                                         \
+      ex(xb, w, 1, 0)[lane] = DST[0][RW - 1];                                                         \
+      ex(xb, w, 1, 1)[lane] = DST[1][RW - 1];                                                         \
       if (lane == 63) errp[xb * 16 + w] = tot63;                                                     \
       __syncthreads();                                                                               \
       itp++;                                                                                         \
@@ -335,7 +381,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int k = 0; k < R; k++) phA[a][k] = phB[a][k];
+        for (int k = 0; k < RW; k++) phA[a][k] = phB[a][k];
     }
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 
@@ -345,7 +391,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
     for (int a = 0; a < 2; a++) {
       const int j = j0 + a;
 #pragma unroll
-      for (int k = 0; k < R; k++) {
+      for (int k = 0; k < RW; k++) {
         const int i = i0 + k;
         const real ph = phA[a][k];
         const real pw = (k > 0) ? phA[a][k > 0 ? k - 1 : 0] : (a == 0 ? hW0 : hW1);
@@ -363,11 +409,11 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
     BCN_PH(3)
     // ---- transport: explicit part of every cell, then the ordered part by one wave ------------
     {
-      real Ac[2][R];
+      real Ac[2][RW];
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int k = 0; k < R; k++) {
+        for (int k = 0; k < RW; k++) {
           const int c = (i0 + k) * SY + j0 + a;
           const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
           const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
@@ -381,26 +427,14 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int k = 0; k < R; k++) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
+          for (int k = 0; k < RW; k++) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
       }
     }
     __syncthreads();
     BCN_PH(4)
-    if (w == 0) {
-      const real c0x = dt * A.ksc * rdx2, c1x = real(0.5) * dt * rdx;
-      const real c0y = dt * A.ksc * rdy2, c1y = real(0.5) * dt * rdy;
-      for (int d = 2; d <= NX + NY; d++) {
-        const int ilo = (d - NY > 1) ? d - NY : 1;
-        const int ihi = (d - 1 < NX) ? d - 1 : NX;
-        for (int i = ilo + lane; i <= ihi; i += 64) {
-          const int c = i * SY + (d - i);
-          const real aw = c0x + c1x * Ul[c], as = c0y + c1y * Vl[c];
-          Tl[c] = Tl[c] + aw * Tl[c - SY] + as * Tl[c - 1];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
+    if (w == 0)
+      transport_chain2<real, NX, NY>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+                                     dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     __syncthreads();
     BCN_PH(5)
   }
@@ -416,7 +450,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int k = 0; k < R; k++) {
+      for (int k = 0; k < RW; k++) {
         const int i = i0 + k, j = j0 + a, c = j * SX + i;
         const real dp = p[a][k] - gp[c];
         if (i == 1) gp[c - 1] += dp;
@@ -433,6 +467,17 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast2_step(NS2DArgs<real> 
   if (tid == 0 && A.obs_out)
     for (int q = 0; q < 6; q++) A.obs_out[(size_t)b * A.n_obs + q] = (real)seg[q] / (real)A.ndt_act;
 #endif
+}
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
+  using G = Fast2Geom<NX, NY, R>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (G::RL != R && w == G::NW - 1)
+    fast2_body<real, NX, NY, R, G::RL, KIND, EQ>(A, smem, w);
+  else
+    fast2_body<real, NX, NY, R, R, KIND, EQ>(A, smem, w);
 }
 
 template <typename real, int NX, int NY, int R, int KIND>
@@ -467,8 +512,8 @@ template <typename real>
 int ns2d_launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   if constexpr (std::is_same<real, float>::value) {
     if (a.nx == 100 && a.ny == 100) {
-      if (a.kind == 1) return launch_fast2<float, 100, 100, 10, 1>(a, batch, s);
-      return launch_fast2<float, 100, 100, 10, 0>(a, batch, s);
+      if (a.kind == 1) return launch_fast2<float, 100, 100, 13, 1>(a, batch, s);
+      return launch_fast2<float, 100, 100, 13, 0>(a, batch, s);
     }
   }
   bcn_set_error("no two-rows-per-lane kernel for this grid");
