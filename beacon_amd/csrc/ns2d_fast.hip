@@ -27,7 +27,7 @@
 #include "ns2d_device.h"
 
 #ifndef BCN_R128
-#define BCN_R128 8
+#define BCN_R128 16
 #endif
 #ifndef BCN_LAG
 #define BCN_LAG 0   // lagged convergence test: measured no faster (1556 vs 1555 cycles per sweep), kept for reference
@@ -383,6 +383,9 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #pragma unroll
     for (int k = 0; k < R; k++) phA[k] = 0;
     bool finalB = false;
+#ifndef BCN_EXP
+#define BCN_EXP 0   // timing experiments only (wrong results): 1 fixed 100 sweeps, 2 no barrier, 4 no LDS exchange, 8 no reduction
+#endif
 #define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                        \
     {                                                                                        \
       real acc = 0;                                                                          \
@@ -393,7 +396,8 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
         DST[k] = ph;                                                                         \
       }                                                                                      \
       if (itp > 0) {                                                                         \
-        const real err = read_lane(row16_sum<real>(eL), 15);                                 \
+        real err = read_lane(row16_sum<real>(eL), 15);                                       \
+        if (BCN_EXP & 1) err = (itp < 100) ? real(1e30) : real(0);                           \
         hW = (w > 0) ? hWr : SRC[0];                                                         \
         hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                \
         if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }             \
@@ -406,15 +410,22 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       DST[R - 1] = pl;                                                                       \
       acc += d0 * d0;                                                                        \
       acc += dl * dl;                                                                        \
-      const real tot63 = wave_sum_lane63<real>(wl * acc + fW * (d0 * d0) + fE * (dl * dl));  \
-      ex(xb, w, 0)[lane] = p0;                                                               \
-      ex(xb, w, 1)[lane] = pl;                                                               \
-      if (lane == 63) errp[xb * 16 + w] = tot63;                                             \
-      __syncthreads();                                                                       \
+      const real part = wl * acc + fW * (d0 * d0) + fE * (dl * dl);                          \
+      const real tot63 = (BCN_EXP & 8) ? part : wave_sum_lane63<real>(part);                 \
+      if (!(BCN_EXP & 4)) {                                                                  \
+        ex(xb, w, 0)[lane] = p0;                                                             \
+        ex(xb, w, 1)[lane] = pl;                                                             \
+        if (lane == 63) errp[xb * 16 + w] = tot63;                                           \
+      }                                                                                      \
+      if (!(BCN_EXP & 2)) __syncthreads();                                                   \
       itp++;                                                                                 \
-      eL = errp[xb * 16 + (lane & 15)];                                                      \
-      hWr = ex(xb, wm, 1)[lane];                                                             \
-      hEr = ex(xb, wp, 0)[lane];                                                             \
+      if (!(BCN_EXP & 4)) {                                                                  \
+        eL = errp[xb * 16 + (lane & 15)];                                                    \
+        hWr = ex(xb, wm, 1)[lane];                                                           \
+        hEr = ex(xb, wp, 0)[lane];                                                           \
+      } else {                                                                               \
+        eL = tot63; hWr = p0; hEr = pl;                                                      \
+      }                                                                                      \
       xb ^= 1;                                                                               \
     }
     for (;;) {
