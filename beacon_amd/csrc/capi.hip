@@ -98,10 +98,14 @@ struct NS2DEnv : bcn_env_s {
   int set_state(const void* buf, int is_device, hipStream_t s) override {
     return copy_state(const_cast<void*>(buf), is_device, s, false);
   }
-  int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; return variant; }
+  int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; launched = nullptr; return variant; }
   void set_mask(const uint8_t* m) override { a.mask = m; }
-  const char* kernel_name() const override { return variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step"; }
+  const char* launched = nullptr;   // name of the kernel the last step dispatched
+  const char* kernel_name() const override {
+    return launched ? launched : (variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step");
+  }
   int launch(hipStream_t s) {
+    a.launched = &launched;
     if (variant == 1) return ns2d_launch_fast<real>(a, batch, s);
     return ns2d_launch_generic<real>(a, batch, s);
   }

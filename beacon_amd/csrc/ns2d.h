@@ -49,6 +49,7 @@ struct NS2DArgs {
   int32_t* sweeps_int;      // handle-owned [B][ndt_act] when the caller passes no sweeps buffer
   void* sched_ctl;          // handle-owned control block of the ticketed chunk scheduler (64 + 4B bytes)
   int sched_q;              // timesteps per chunk
+  const char** launched;    // host side: receives the name of the kernel the launcher dispatched (may be NULL)
 };
 
 // launchers (one per translation unit)

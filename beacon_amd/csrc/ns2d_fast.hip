@@ -386,6 +386,10 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #ifndef BCN_EXP
 #define BCN_EXP 0   // timing experiments only (wrong results): 1 fixed 100 sweeps, 2 no barrier, 4 no LDS exchange, 8 no reduction
 #endif
+#ifndef BCN_ERRB
+#define BCN_ERRB 1   // 1: broadcast-read the NW error partials and add them per lane; 0: DPP row reduction
+#endif
+    real eB[NW];
 #define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                        \
     {                                                                                        \
       real acc = 0;                                                                          \
@@ -396,8 +400,15 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
         DST[k] = ph;                                                                         \
       }                                                                                      \
       if (itp > 0) {                                                                         \
-        real err = read_lane(row16_sum<real>(eL), 15);                                       \
-        if (BCN_EXP & 1) err = (itp < 100) ? real(1e30) : real(0);                           \
+        real err;                                                                            \
+        if (BCN_ERRB) {   /* every lane sums the NW partials it read by broadcast */         \
+          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                               \
+            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st]; \
+          err = read_lane(eB[0], 0);                                                         \
+        } else {                                                                             \
+          err = read_lane(row16_sum<real>(eL), 15);                                          \
+        }                                                                                    \
+        if (BCN_EXP & 1) err = (itp < 100) ? real(1e30) : err * real(0);                     \
         hW = (w > 0) ? hWr : SRC[0];                                                         \
         hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                \
         if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }             \
@@ -420,11 +431,15 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       if (!(BCN_EXP & 2)) __syncthreads();                                                   \
       itp++;                                                                                 \
       if (!(BCN_EXP & 4)) {                                                                  \
-        eL = errp[xb * 16 + (lane & 15)];                                                    \
+        if (BCN_ERRB) {                                                                      \
+          _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 16 + q];          \
+        } else {                                                                             \
+          eL = errp[xb * 16 + (lane & 15)];                                                  \
+        }                                                                                    \
         hWr = ex(xb, wm, 1)[lane];                                                           \
         hEr = ex(xb, wp, 0)[lane];                                                           \
       } else {                                                                               \
-        eL = tot63; hWr = p0; hEr = pl;                                                      \
+        eL = tot63; eB[0] = tot63; hWr = p0; hEr = pl;                                                    \
       }                                                                                      \
       xb ^= 1;                                                                               \
     }
@@ -678,6 +693,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, sizeof(SchedCtl) + (size_t)batch * sizeof(unsigned int), s));
     hipLaunchKernelGGL(ks, dim3(sched_grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
     BCN_HIP(hipGetLastError());
+    if (a.launched) *a.launched = "ns2d_fast_sched";
     return BCN_OK;
   }
   // split only when replicas outnumber the CUs (otherwise every replica starts at once and
@@ -704,6 +720,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   }
   BCN_HIP(hipGetLastError());
+  if (a.launched) *a.launched = "ns2d_fast_step";
   return BCN_OK;
 }
 

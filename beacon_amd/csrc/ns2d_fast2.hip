@@ -498,6 +498,7 @@ int launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   }
   BCN_HIP(hipGetLastError());
+  if (a.launched) *a.launched = "ns2d_fast2_step";
   return BCN_OK;
 }
 

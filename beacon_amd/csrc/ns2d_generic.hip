@@ -430,6 +430,7 @@ int launch_step(const NS2DArgs<real>& a_in, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(batch), dim3(NT), lds, s, a);
   }
   BCN_HIP(hipGetLastError());
+  if (a.launched) *a.launched = "ns2d_generic_step";
   return BCN_OK;
 }
 

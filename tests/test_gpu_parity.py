@@ -198,6 +198,63 @@ def test_rayleigh_fast_identical_replicas_are_bit_identical(cfg, dtype):
     env.close()
 
 
+def test_rayleigh_100x100_fast2_vs_oracle_and_generic():
+    """ns2d_fast2 (two rows per lane, uneven column strips) in its rayleigh instantiation: L = H = 2
+    -> 100x100, f32, seeded synthetic start, 2 x 12 timesteps.  Against the f64 oracle per replica
+    (5e-5, p 50x looser as above), against the generic kernel, and replicas with identical inputs
+    must stay bit-identical (hand-written DPP).  Sweep counts within max(4, 4 %): the stop test
+    looks at increments of ~1e-6 on a phi of O(0.1), so float32 rounding moves the crossing a little
+    (a start with grid-scale noise in the velocities moves it by tens of percent: phi is O(1) there
+    and the all-Neumann problem is only compatible to rounding)."""
+    nx = ny = 100
+    rng = np.random.default_rng(7)
+    init = np.zeros((4, nx + 2, ny + 2))
+    y = (np.arange(ny + 2) - 0.5) / ny
+    x = (np.arange(nx + 2) - 0.5) / nx
+    init[3] = (0.5 - y)[None, :] + 0.1 * np.sin(4 * np.pi * x)[:, None] * np.sin(np.pi * y)[None, :] \
+        + 1e-3 * rng.standard_normal((nx + 2, ny + 2))
+    B, NDT = 6, 12
+    acts = rng.uniform(-1, 1, (2, B, 10))
+    acts[:, 4:] = acts[:, 0:1]                      # replicas 4, 5 repeat replica 0
+    env = V.VecRayleigh(B, DEV, "f32", init, L=2.0, H=2.0)
+    env.set_ndt_act(NDT)
+    _variant(env, 1)
+    env.reset()
+    state0 = env.get_state().clone()
+    oracles = [O.rayleigh(init_fields=init, L=2.0, H=2.0) for _ in range(4)]
+    for o in oracles:
+        o.cfg.ndt_act = NDT
+        o.reset()
+    fast = []
+    for k in range(2):
+        obs, rwd, _, _, _ = env.step(acts[k])
+        env.check_status()
+        assert env.kernel_name == "ns2d_fast2_step"
+        raw = env.get_state()
+        st, sw = dev2ref(raw), env.sweeps.cpu().numpy()
+        for b in (4, 5):
+            assert bool((raw[b] == raw[0]).all()) and np.array_equal(sw[b], sw[0])
+        for b, o in enumerate(oracles):
+            ob, rw, _, _, _ = o.step(acts[k, b].tolist())
+            for i, F in enumerate("uvpT"):
+                assert maxdiff(st[b][i], o.st[i]) <= 5e-5 * (50 if F == "p" else 1), (k, b, F)
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5
+            assert abs(float(rwd[b]) - rw) <= 2e-4
+            assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(4, 0.04 * o.itp)), (sw[b], o.itp)
+        fast.append((raw.clone(), sw.copy()))
+    assert env.set_variant(0) == 0
+    env.set_state(state0)
+    env.set_stp(0)
+    for k in range(2):
+        env.step(acts[k])
+        assert env.kernel_name == "ns2d_generic_step"
+        raw = env.get_state()
+        for i, F in enumerate("uvpT"):
+            assert float((raw[:, i] - fast[k][0][:, i]).abs().max()) <= 5e-5 * (50 if F == "p" else 1), (k, F)
+        assert np.all(np.abs(env.sweeps.cpu().numpy() - fast[k][1]) <= np.maximum(4, 0.04 * fast[k][1]))
+    env.close()
+
+
 def test_rayleigh_episode_end_and_overflow():
     g = golden("rayleigh_default")
     env = V.VecRayleigh(2, DEV, "f64", _ray_init(g))
@@ -281,6 +338,41 @@ def test_mixing_synth_all_actions_f64():
         for i, F in enumerate("uvpC"):
             assert maxdiff(st[a][i], g["a%d_%s" % (a, F)]) <= F64_TOL * (50 if F == "p" else 1)
         assert maxdiff(obs[a].cpu().numpy(), g["a%d_obs" % a]) <= F64_TOL
+    env.close()
+
+
+def test_mixing_fast2_vs_generic_and_identical_replicas():
+    """mixing 100x100 f32 on ns2d_fast2 from the synthetic developed state: 16 replicas per action
+    (bit-identical within a group, sweep counts included), then the generic kernel on the same
+    inputs (5e-5 on u, v, C; p 50x looser; sweeps within max(3, 1 %))."""
+    g = golden("mixing_synth")
+    B, NDT = 64, 6
+    env = V.VecMixing(B, DEV, "f32")
+    env.set_ndt_act(NDT)
+    env.reset()
+    st0 = np.stack([ref_to_dev(g[k]) for k in ("u0", "v0", "p0", "C0")])
+    acts = np.repeat(np.arange(4), 16)
+    runs = {}
+    for variant in (1, 0):
+        assert env.set_variant(variant) == variant
+        env.set_state(np.tile(st0[None], (B, 1, 1, 1)))
+        env.set_stp(0)
+        out = []
+        for k in range(2):
+            env.step(acts)
+            env.check_status()
+            out.append((env.get_state().clone(), env.sweeps.cpu().numpy().copy()))
+        assert env.kernel_name == ("ns2d_fast2_step" if variant else "ns2d_generic_step")
+        runs[variant] = out
+    for k in range(2):
+        st, sw = runs[1][k]
+        for a in range(4):
+            grp = slice(16 * a, 16 * a + 16)
+            assert bool((st[grp] == st[16 * a:16 * a + 1]).all()) and bool((sw[grp] == sw[16 * a]).all())
+        gs, gw = runs[0][k]
+        for i, F in enumerate("uvpC"):
+            assert float((st[:, i] - gs[:, i]).abs().max()) <= 5e-5 * (50 if F == "p" else 1), (k, F)
+        assert np.all(np.abs(sw - gw) <= np.maximum(3, 0.01 * gw))
     env.close()
 
 
