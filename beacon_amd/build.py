@@ -21,7 +21,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=h
 
 # per-file flags.  ns2d_fast: the SLP vectoriser packs the Jacobi arithmetic into v_pk_* ops at the
 # price of many register shuffles -- measured slower than the scalar stream on gfx950.
-FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize"], "ns2d_fast2.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on"], "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on"]}
 
 
 def hipcc():

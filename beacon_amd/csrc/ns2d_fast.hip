@@ -25,6 +25,7 @@
 #include "bcn_dpp.h"
 #include "ns2d.h"
 #include "ns2d_device.h"
+#include "ns2d_sched.h"
 
 #ifndef BCN_R128
 #define BCN_R128 16
@@ -188,6 +189,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
   const real wl = active ? real(1) + (j == 1 ? 1 : 0) + ((j == NY && KIND == 0) ? 1 : 0) : real(0);
   const real fW = (active && w == 0) ? real(1) : real(0);
   const real fE = (active && w == NW - 1) ? real(1) : real(0);
+  const real cW = wl + fW, cE = wl + fE;   // weights of the strip's first / last column (ghost columns included)
   // coefficient of the lane's own value from the y-ghosts (bottom: always Neumann; top: rayleigh)
   const real cBy = cy * (real)((lane == 0 ? 1 : 0) + ((lane == NY - 1 && KIND == 0) ? 1 : 0));
   const real actf = active ? real(1) : real(0);
@@ -399,6 +401,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
         acc += d * d;                                                                        \
         DST[k] = ph;                                                                         \
       }                                                                                      \
+      const real pI = wl * acc;   /* the edge cells join below: short tail in front of the barrier */ \
       if (itp > 0) {                                                                         \
         real err;                                                                            \
         if (BCN_ERRB) {   /* every lane sums the NW partials it read by broadcast */         \
@@ -419,9 +422,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
       DST[0] = p0;                                                                           \
       DST[R - 1] = pl;                                                                       \
-      acc += d0 * d0;                                                                        \
-      acc += dl * dl;                                                                        \
-      const real part = wl * acc + fW * (d0 * d0) + fE * (dl * dl);                          \
+      const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
       const real tot63 = (BCN_EXP & 8) ? part : wave_sum_lane63<real>(part);                 \
       if (!(BCN_EXP & 4)) {                                                                  \
         ex(xb, w, 0)[lane] = p0;                                                             \
@@ -557,79 +558,16 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
   fast_unit<real, NX, NY, R, KIND, EQ>(A, b, A.it_begin, A.it_end, A.first_chunk != 0, A.last_chunk != 0, smem);
 }
 
-// ---- ticketed chunk scheduler ----------------------------------------------------------------
-// With more replicas than CUs a replica is no longer tied to one workgroup: the step is cut into
-// chunks of A.sched_q timesteps and persistent workgroups (one per CU) draw (chunk, replica) units
-// from a global ticket counter in chunk-major order, so every CU stays busy until the slowest
-// replica's chain of chunks ends (makespan ~ max(critical path, mean) instead of the sum of whichever
-// two replicas a CU happened to get).  A replica's state moves between CUs through HBM; the hand-off
-// follows the agent-scope release/acquire recipe of the CDNA programming guide (Guideline 16):
-//   producer: stores -> workgroup barrier -> lane 0: fence(release, agent); s_waitcnt vmcnt(0);
-//             relaxed agent store progress[r] = c+1
-//   consumer: lane 0 polls progress[r] (relaxed, agent, s_sleep) -> fence(acquire, agent);
-//             s_waitcnt vmcnt(0) -> workgroup barrier -> plain loads.
-// Tickets are drawn in order, so when unit (c, r) is drawn unit (c-1, r) has already been drawn by
-// a workgroup that never waits on a later ticket: every wait is finite whatever the residency.
-// Spins are bounded anyway: on timeout the abort word is set, every workgroup drains, and the
-// affected replicas report BCN_ST_ITMAX.
-struct SchedCtl {
-  unsigned int ticket;
-  unsigned int abort;
-  unsigned int pad[14];
-  unsigned int progress[1];   // [B]
-};
-
+// ---- ticketed chunk scheduler (ns2d_sched.h) ---------------------------------------------------
 template <typename real, int NX, int NY, int R, int KIND, bool EQ>
 __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
                                                           2 * FastGeom<NX, NY, R>::NW * 2 * 64 + 128);
-  unsigned int& s_ticket = s_words[0];
-  unsigned int& s_ok = s_words[1];
-  const unsigned int total = (unsigned int)batch * (unsigned int)nchunk;
-  for (;;) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl->ticket, 1u);
-    __syncthreads();
-    const unsigned int t = s_ticket;
-    if (t >= total) break;
-    const int c = (int)(t / (unsigned int)batch), b = (int)(t % (unsigned int)batch);
-    const bool skip = A.mask && !A.mask[b];
-    if (threadIdx.x == 0) {
-      unsigned int ok = 1;
-      if (!skip && c > 0) {
-        unsigned int spins = 0;
-        while (__hip_atomic_load(&ctl->progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)c) {
-          __builtin_amdgcn_s_sleep(32);
-          if (++spins > (1u << 24) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = 0;
-            break;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      s_ok = ok;
-    }
-    __syncthreads();
-    if (!skip) {
-      if (s_ok) {
-        const int it0 = c * A.sched_q;
-        const int it1 = (c == nchunk - 1) ? A.ndt_act : it0 + A.sched_q;
-        fast_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, c == 0, c == nchunk - 1, smem);
-      } else if (threadIdx.x == 0 && A.status) {
-        A.status[b] = BCN_ST_ITMAX;
-      }
-      __syncthreads();   // every wave's stores are issued and waited for (barrier implies vmcnt(0))
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&ctl->progress[b], (unsigned int)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();     // s_ticket / s_ok are rewritten next trip
-  }
+  ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
+    fast_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
+  });
 }
 
 // ---- LPT ordering between the two launches of one step ---------------------------------------
@@ -668,19 +606,8 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
-  // ---- scheduling mode: BCN_SCHED = 0 plain launch, 1 two-launch LPT split, 2 ticketed chunks (default)
-  static int mode = -1, sched_grid = 0, ncu_dev = 256, SQ = 10;
-  if (mode < 0) {
-    const char* e = getenv("BCN_SCHED");
-    const char* g = getenv("BCN_SCHED_GRID");
-    const char* q = getenv("BCN_SCHED_Q");
-    if (q && atoi(q) > 0) SQ = atoi(q);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, dev);
-    sched_grid = g ? atoi(g) : ncu_dev;
-    mode = e ? atoi(e) : 2;
-  }
+  const SchedParams& sp = ns2d_sched_params();
+  const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
     auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ>;
     static bool attr_set2 = false;

@@ -22,6 +22,7 @@
 #include "bcn_dpp.h"
 #include "ns2d.h"
 #include "ns2d_device.h"
+#include "ns2d_sched.h"
 
 namespace {
 
@@ -91,7 +92,9 @@ __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real*
 }
 
 template <typename real, int NX, int NY, int R, int RW, int KIND, bool EQ>
-__device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, const int w) {
+__device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, const int w, const int b,
+                                           const int it_begin, const int it_end, const bool first_chunk,
+                                           const bool last_chunk) {
   using G = Fast2Geom<NX, NY, R>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, LH = G::LH;
   real* exch = reinterpret_cast<real*>(smem);
@@ -102,8 +105,6 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   real* Vl = Ul + SZ;
   real* Tl = Vl + SZ;
 
-  const int b = blockIdx.x;
-  if (A.mask && !A.mask[b]) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const bool active = lane < LH;
   const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
@@ -134,7 +135,9 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 
   // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----------
   real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
-  if (KIND == 0) {
+  if (KIND == 0 && !first_chunk) {   // later chunks of a scheduled step reuse the conditioned vector
+    if (tid < A.n_sgts) sact[tid] = A.a_last[(size_t)b * A.n_sgts + tid];
+  } else if (KIND == 0) {
     const int n = A.n_sgts;
     const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
     real mean = 0;
@@ -153,9 +156,9 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
     }
   } else {
-    const int act = A.iactions ? A.iactions[b] : A.ia_last[b];
+    const int act = (A.iactions && first_chunk) ? A.iactions[b] : A.ia_last[b];
     __syncthreads();
-    if (tid == 0) A.ia_last[b] = act;
+    if (tid == 0 && first_chunk) A.ia_last[b] = act;
     if (act == 0) { u_b = A.u_max; u_t = -A.u_max; }
     if (act == 1) { u_b = -A.u_max; u_t = A.u_max; }
     if (act == 2) { v_r = A.u_max; v_l = -A.u_max; }
@@ -176,6 +179,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   const real wl1 = active ? real(1) + ((lane == LH - 1 && KIND == 0) ? 1 : 0) : real(0);
   const real fW = (active && w == 0) ? real(1) : real(0);
   const real fE = (active && w == NW - 1) ? real(1) : real(0);
+  // weights of the strip's first / last column (the ghost column next to a wall column counts too)
+  const real cW0 = wl0 * (1 + fW), cW1 = wl1 * (1 + fW), cE0 = wl0 * (1 + fE), cE1 = wl1 * (1 + fE);
   const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
 
   int status = 0;
@@ -187,7 +192,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #else
 #define BCN_PH(x)
 #endif
-  for (int it = 0; it < A.ndt_act && status == 0; it++) {
+  if (!first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
+  for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202 / mixing.py:153-171) ------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
       Ul[1 * SY + jj] = 0;
@@ -305,7 +311,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
       for (int k = 0; k < RW; k++) phA[a][k] = 0;
     real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
-    real eL = 0, hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
+    real eB[NW], hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
     int itp = 0;
     bool finalB = false;
     // lower row (a = 0): south = lane below's upper row (DPP), north = own upper row;
@@ -324,13 +330,15 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         ph1 = cxl * (EV##1 + WV##1) + (cyl * sn1 + (cB1 * c1 + nb[1][K]));                           \
       }                                                                                              \
       const real d0 = ph0 - c0, d1 = ph1 - c1;                                                       \
-      acc0 += d0 * d0;                                                                               \
-      acc1 += d1 * d1;                                                                               \
       if (K == 0) { dW0 = d0 * d0; dW1 = d1 * d1; }                                                  \
-      if (K == RW - 1) { dE0 = d0 * d0; dE1 = d1 * d1; }                                              \
+      else if (K == RW - 1) { dE0 = d0 * d0; dE1 = d1 * d1; }                                        \
+      else { acc0 += d0 * d0; acc1 += d1 * d1; }                                                     \
       DST[0][K] = ph0;                                                                               \
       DST[1][K] = ph1;                                                                               \
     }
+#ifndef BCN2_ERRB
+#define BCN2_ERRB 0   // 1: broadcast-read the NW error partials and add them per lane; 0: DPP row reduction (measured faster here)
+#endif
 #define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                                \
     {                                                                                                \
       real acc0 = 0, acc1 = 0, dW0 = 0, dW1 = 0, dE0 = 0, dE1 = 0;                                   \
@@ -338,8 +346,16 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         const real e0 = SRC[0][k + 1], e1 = SRC[1][k + 1], w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];  \
         BCN_CELL(DST, SRC, k, e, w)                                                                  \
       }                                                                                              \
+      const real pI = wl0 * acc0 + wl1 * acc1;   /* the edge columns join below: short tail */        \
       if (itp > 0) {                                                                                 \
-        const real err = read_lane(row16_sum<real>(eL), 15);                                         \
+        real err;                                                                                    \
+        if (BCN2_ERRB) { /* every lane adds the NW partials it read by broadcast */                  \
+          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                       \
+            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st];         \
+          err = read_lane(eB[0], 0);                                                                 \
+        } else {                                                                                     \
+          err = read_lane(row16_sum<real>(eB[0]), 15);                                               \
+        }                                                                                            \
         hW0 = (w > 0) ? hW0r : SRC[0][0];                                                            \
         hW1 = (w > 0) ? hW1r : SRC[1][0];                                                            \
         hE0 = (w < NW - 1) ? hE0r : SRC[0][RW - 1];                                                   \
@@ -355,7 +371,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         const real e0 = hE0, e1 = hE1, w0 = SRC[0][RW - 2], w1 = SRC[1][RW - 2];                       \
         BCN_CELL(DST, SRC, RW - 1, e, w)                                                              \
       }                                                                                              \
-      const real part = wl0 * acc0 + wl1 * acc1 + fW * (wl0 * dW0 + wl1 * dW1) + fE * (wl0 * dE0 + wl1 * dE1); \
+      const real part = pI + (cW0 * dW0 + cW1 * dW1) + (cE0 * dE0 + cE1 * dE1);                      \
       const real tot63 = wave_sum_lane63<real>(part);                                                \
       ex(xb, w, 0, 0)[lane] = DST[0][0];                                                             \
       ex(xb, w, 0, 1)[lane] = DST[1][0];                                                             \
@@ -364,7 +380,11 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       if (lane == 63) errp[xb * 16 + w] = tot63;                                                     \
       __syncthreads();                                                                               \
       itp++;                                                                                         \
-      eL = errp[xb * 16 + (lane & 15)];                                                              \
+      if (BCN2_ERRB) {                                                                               \
+        _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 16 + q];                    \
+      } else {                                                                                       \
+        eB[0] = errp[xb * 16 + (lane & 15)];                                                         \
+      }                                                                                              \
       hW0r = ex(xb, wm, 1, 0)[lane];                                                                 \
       hW1r = ex(xb, wm, 1, 1)[lane];                                                                 \
       hE0r = ex(xb, wp, 0, 0)[lane];                                                                 \
@@ -461,45 +481,84 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       }
   }
   __syncthreads();
-  ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
+  if (last_chunk) {
+    ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
+  } else if (tid == 0 && A.status) {
+    A.status[b] = status;
+  }
 #ifdef BCN_STAMP   // diagnostic build only: cycles per timestep of each phase over the first obs entries
   __syncthreads();
   if (tid == 0 && A.obs_out)
-    for (int q = 0; q < 6; q++) A.obs_out[(size_t)b * A.n_obs + q] = (real)seg[q] / (real)A.ndt_act;
+    for (int q = 0; q < 6; q++) A.obs_out[(size_t)b * A.n_obs + q] = (real)seg[q] / (real)(it_end - it_begin);
 #endif
 }
 
 template <typename real, int NX, int NY, int R, int KIND, bool EQ>
-__global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
+__device__ __forceinline__ void fast2_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
+                                           const bool first_chunk, const bool last_chunk, char* smem) {
   using G = Fast2Geom<NX, NY, R>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (G::RL != R && w == G::NW - 1)
-    fast2_body<real, NX, NY, R, G::RL, KIND, EQ>(A, smem, w);
+    fast2_body<real, NX, NY, R, G::RL, KIND, EQ>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
   else
-    fast2_body<real, NX, NY, R, R, KIND, EQ>(A, smem, w);
+    fast2_body<real, NX, NY, R, R, KIND, EQ>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
 }
 
-template <typename real, int NX, int NY, int R, int KIND>
-int launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+// plain launch: one workgroup per replica, the whole action step
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
+  fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, 0, A.ndt_act, true, true, smem);
+}
+
+// ticketed chunk scheduler (ns2d_sched.h): persistent workgroups draw (chunk, replica) units
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch,
+                                                                          int nchunk) {
+  using G = Fast2Geom<NX, NY, R>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // two words at the end of the `red` scratch row (block_sum uses red[0..NW), the transport sink red[16..17])
+  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) + G::EXCH + 96 + 24);
+  ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
+    fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
+  });
+}
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   using G = Fast2Geom<NX, NY, R>;
   const size_t lds = G::lds_elems() * sizeof(real);
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
-  if (a.cx == a.cy) {
-    auto k = ns2d_fast2_step<real, NX, NY, R, KIND, true>;
-    static bool set = false;
-    if (!set) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
-    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
-  } else {
-    auto k = ns2d_fast2_step<real, NX, NY, R, KIND, false>;
-    static bool set = false;
-    if (!set) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
-    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  const SchedParams& sp = ns2d_sched_params();
+  if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * sp.q && a.sched_ctl) {
+    auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ>;
+    static bool set2 = false;
+    if (!set2) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set2 = true; }
+    const int nchunk = a.ndt_act / sp.q;
+    c.sched_q = sp.q;
+    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, sizeof(SchedCtl) + (size_t)batch * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(ks, dim3(sp.grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
+    BCN_HIP(hipGetLastError());
+    if (a.launched) *a.launched = "ns2d_fast2_sched";
+    return BCN_OK;
   }
+  auto k = ns2d_fast2_step<real, NX, NY, R, KIND, EQ>;
+  static bool set = false;
+  if (!set) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+  hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   BCN_HIP(hipGetLastError());
   if (a.launched) *a.launched = "ns2d_fast2_step";
   return BCN_OK;
+}
+
+template <typename real, int NX, int NY, int R, int KIND>
+int launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  // dx == dy (every reference configuration): one multiply per cell instead of two
+  if (a.cx == a.cy) return launch_fast2_eq<real, NX, NY, R, KIND, true>(a, batch, s);
+  return launch_fast2_eq<real, NX, NY, R, KIND, false>(a, batch, s);
 }
 
 }  // namespace

@@ -3,6 +3,8 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from beacon_amd import build
 extra = sys.argv[1:]
+for x in [x for x in extra if x.startswith("-ffp-contract=")]:      # per-file flags come last on the command line
+    build.FILE_FLAGS = {k: [f for f in v if not f.startswith("-ffp-contract=")] + [x] for k, v in build.FILE_FLAGS.items()}
 build.FLAGS.extend(["-DBCN_STAMP"] + extra); build.build_lib(force=True)
 from beacon_amd import vec as V
 z = np.load("tests/golden/rayleigh_128x64_init.npz")

@@ -376,6 +376,44 @@ def test_mixing_fast2_vs_generic_and_identical_replicas():
     env.close()
 
 
+def test_mixing_fast2_ticket_scheduler_matches_single_launch():
+    """ns2d_fast2_sched (persistent workgroups drawing 10-timestep chunks, here 5 workgroups for 24
+    replicas) against the plain one-workgroup-per-replica launch: obs, rewards, sweep counts and
+    interior fields bit for bit (p ghost cells: one float32 rounding, see the rayleigh test above)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from beacon_amd import vec as V\n"
+        "env = V.VecMixing(24, 'cuda:0', 'f32')\n"
+        "env.set_ndt_act(60)\n"
+        "env.reset()\n"
+        "a = np.random.default_rng(5).integers(0, 4, (2, 24))\n"
+        "for k in range(2): obs, rwd, *_ = env.step(a[k])\n"
+        "env.check_status()\n"
+        "assert env.kernel_name == sys.argv[2], env.kernel_name\n"
+        "np.save(sys.argv[1], np.concatenate([obs.cpu().numpy().ravel(), rwd.cpu().numpy(),"
+        " env.get_state().cpu().numpy().ravel(), env.sweeps.cpu().numpy().ravel().astype(np.float32)]))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, kname, extra in (("single", "ns2d_fast2_step", dict(BCN_SCHED="0")),
+                              ("ticket", "ns2d_fast2_sched", dict(BCN_SCHED="2", BCN_SCHED_GRID="5"))):
+        path = "/tmp/bcn_mix_%s.npy" % tag
+        r = subprocess.run([sys.executable, "-c", code, path, kname], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    B, ndt = 24, 60
+    n_head = B * 192 + B
+    assert np.array_equal(outs[0][:n_head], outs[1][:n_head])                         # obs, rwd
+    assert np.array_equal(outs[0][-B * ndt:], outs[1][-B * ndt:])                     # sweeps
+    st = [o[n_head:-B * ndt].reshape(B, 4, 102, 102) for o in outs]
+    for f in (0, 1, 3):
+        assert np.array_equal(st[0][:, f], st[1][:, f])
+    assert np.array_equal(st[0][:, 2, 1:-1, 1:-1], st[1][:, 2, 1:-1, 1:-1])
+    assert np.max(np.abs(st[0][:, 2] - st[1][:, 2])) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # burgers
 # ---------------------------------------------------------------------------------------------
