@@ -6,6 +6,8 @@
 // exit.  Inlet noise is an explicit input (the reference draws it from numpy's global
 // stream: burgers.py:127, shkadov.py:204).  Citations: file:line into
 // /root/reference/beacon/.
+#include <stdlib.h>
+
 #include "env1d.h"
 
 namespace {
@@ -21,6 +23,17 @@ template <typename real>
 __device__ __forceinline__ real np_max(real a, real b) {
   return (a > b || a != a) ? a : b;
 }
+
+// float32 kernels: divisions outside burgers' limiter and BDF2 update use a * v_rcp_f32(b) (~1.5 ulp,
+// operands are O(1): no denormal scaling needed) and 1/dx is a multiplication; IEEE division costs ~10
+// VALU instructions and made up 20-30 % of the step time (scripts/exp_1ddiv.sh).  float64 keeps the
+// reference's divisions.
+template <typename real> __device__ __forceinline__ real fdiv(real a, real b) { return a / b; }
+template <> __device__ __forceinline__ float fdiv<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+template <typename real> __device__ __forceinline__ real divc(real a, real c, real rc) { (void)rc; return a / c; }
+template <> __device__ __forceinline__ float divc<float>(float a, float c, float rc) { (void)c; return a * rc; }
+template <typename real> __device__ __forceinline__ real fsqrt(real a) { return sqrt(a); }
+template <> __device__ __forceinline__ float fsqrt<float>(float a) { return __builtin_amdgcn_sqrtf(a); }
 
 template <typename real, int NT>
 __device__ __forceinline__ void finish(const Env1DArgs<real>& A, int b, real rwd, bool blow, real blow_rwd,
@@ -105,9 +118,10 @@ __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
       const int c = i0 + k;
       real fp = e[k + 2] + real(0.5) * ph[k + 1] * (e[k + 3] - e[k + 2]);
       real fm = e[k + 1] + real(0.5) * ph[k] * (e[k + 2] - e[k + 1]);
-      real du = (fp - fm) / A.dx;
+      real du = divc<real>(fp - fm, A.dx, A.rdx);
       real rhs = e[k + 2] * du;
       if (c == A.ctrl_pos) rhs += force;              // :143
+      // true division: float(1/3) is 3e-8 too large, a bias that compounds to 2e-4 over 12400 timesteps
       real un = (real(4) * up[k] - upp[k] - real(2) * A.dt * rhs) / real(3);  // :246-249
       if (c >= 1 && c <= n - 2) u[k] = un;
     }
@@ -230,15 +244,15 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
     eq[K + 2] = getq(i0 + K);
     real e2[K + 3];  // q^2/(h+eps) at cells i0-2 .. i0+K (:213)
 #pragma unroll
-    for (int k = 0; k < K + 3; k++) e2[k] = eq[k] * eq[k] / (eh[k] + A.eps);
+    for (int k = 0; k < K + 3; k++) e2[k] = fdiv<real>(eq[k] * eq[k], eh[k] + A.eps);
     // minmod limiter at cells i0-1 .. i0+K-1 (zero at both array ends, :497-500)
     real pq[K + 1], p2[K + 1];
 #pragma unroll
     for (int k = 0; k <= K; k++) {
       const int c = i0 - 1 + k;
       const bool edge = (c <= 0 || c >= n - 1);
-      real r1 = (eq[k + 1] - eq[k]) / (eq[k + 2] - eq[k + 1] + real(1.0e-8));
-      real r2 = (e2[k + 1] - e2[k]) / (e2[k + 2] - e2[k + 1] + real(1.0e-8));
+      real r1 = fdiv<real>(eq[k + 1] - eq[k], eq[k + 2] - eq[k + 1] + real(1.0e-8));
+      real r2 = fdiv<real>(e2[k + 1] - e2[k], e2[k + 2] - e2[k + 1] + real(1.0e-8));
       pq[k] = edge ? real(0) : np_clip01(r1);
       p2[k] = edge ? real(0) : np_clip01(r2);
     }
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
         d3 = (-eh[k + 5] + real(6) * eh[k + 4] - real(12) * eh[k + 3] + real(10) * eh[k + 2] -
               real(3) * eh[k + 1]) * (real(0.5) * rdx3);
       // rhsq (:507-512)
-      real rqn = real(1.2) * d2 - A.delta_p * (h[k] * (d3 + real(1)) - q[k] / (h[k] * h[k] + A.eps));
+      real rqn = real(1.2) * d2 - A.delta_p * (h[k] * (d3 + real(1)) - fdiv<real>(q[k], h[k] * h[k] + A.eps));
       // jets (:223-232): parabolic profile on [s, e], s = jet_pos + j*space - hw, e = s + 2 hw
       const int rel = c - jet0;
       if (rel >= 0) {
@@ -393,9 +407,9 @@ __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
     real ev[K + 2], eg[K + 2], es[K + 2];  // v, q^2/h + g h^2/2, |v| + sqrt(g h) (:193-199)
 #pragma unroll
     for (int k = 0; k < K + 2; k++) {
-      ev[k] = eq[k] / eh[k];
-      eg[k] = eq[k] * eq[k] / eh[k] + real(0.5) * g * (eh[k] * eh[k]);
-      es[k] = bcn_abs(ev[k]) + sqrt(g * eh[k]);
+      ev[k] = fdiv<real>(eq[k], eh[k]);
+      eg[k] = fdiv<real>(eq[k] * eq[k], eh[k]) + real(0.5) * g * (eh[k] * eh[k]);
+      es[k] = bcn_abs(ev[k]) + fsqrt<real>(g * eh[k]);
     }
     const real alpha = fmin((real)it / (real)A.n_interp, real(1));
     const real uu = (real(1) - alpha) * uo + alpha * un;
@@ -409,8 +423,8 @@ __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
       real fhd = real(0.5) * (eq[k + 1] + eq[k + 2]) - real(0.5) * cr * (eh[k + 2] - eh[k + 1]);
       real fqg = real(0.5) * (eg[k] + eg[k + 1]) - real(0.5) * cl * (eq[k + 1] - eq[k]);
       real fqd = real(0.5) * (eg[k + 1] + eg[k + 2]) - real(0.5) * cr * (eq[k + 2] - eq[k + 1]);
-      real rhn = (fhd - fhg) / A.dx;
-      real rqn = (fqd - fqg) / A.dx + uu * A.amp;      // :213-218
+      real rhn = divc<real>(fhd - fhg, A.dx, A.rdx);
+      real rqn = divc<real>(fqd - fqg, A.dx, A.rdx) + uu * A.amp;      // :213-218
       if (c >= 1 && c <= nx) {
         const real rhp = rh[k], rqp = rq[k];
         rh[k] = rhn;
@@ -449,17 +463,53 @@ __global__ __launch_bounds__(NT) void sloshing_reset_k(Env1DArgs<real> A) {
   (void)sloshing_obs_rwd<real, NT>(A, b, real(0), red, &blow);
 }
 
-// ---- (K, NT) selection: NT*K >= n -----------------------------------------------------------
+// ---- (K, NT) selection: NT*K >= n ------------------------------------------------------------
+// K cells per thread, NT threads per replica.  Fewer cells per thread = more waves per replica: the
+// per-timestep work of a thread is a dependent chain (halo exchange -> stencil -> update), so small
+// batches of short grids want K small (more waves per SIMD to hide it), long grids want K = 8 (less
+// halo traffic per cell).  pick_k(): 4 cells per thread up to 4096 cells (8 beyond), 2 when that leaves
+// the chip with fewer than ~8 waves per CU; BCN_1D_K overrides (tests / tuning).
+inline int pick_k(int n, int batch) {
+  static int force = -1, ncu = 256;
+  if (force < 0) {
+    const char* e = getenv("BCN_1D_K");
+    force = e ? atoi(e) : 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  if (force == 1 || force == 2 || force == 4 || force == 8) return (n <= force * 1024) ? force : 8;
+  // measured (scripts/exp_1dk.sh, B=1024): burgers N=512 K=8/4/2/1 -> 0.121/0.099/0.096/0.103 ms,
+  // sloshing N=202 0.148/0.081/0.079/0.090 ms, shkadov N=4096 K=8/4 -> 1.146/0.937 ms
+  int k = (n > 4096) ? 8 : 4;
+  if (k == 4 && n <= 2048 && (long)batch * ((n + 255) / 256) < 8L * ncu) k = 2;
+  return k;
+}
+
+#define BCN_LAUNCH_NT(KERNEL, K_, A, BATCH, STREAM)                                                             \
+  do {                                                                                                          \
+    const int n__ = (A).n;                                                                                      \
+    if (n__ <= K_ * 64) hipLaunchKernelGGL((KERNEL<real, K_, 64>), dim3(BATCH), dim3(64), 0, STREAM, A);        \
+    else if (n__ <= K_ * 128) hipLaunchKernelGGL((KERNEL<real, K_, 128>), dim3(BATCH), dim3(128), 0, STREAM, A); \
+    else if (n__ <= K_ * 256) hipLaunchKernelGGL((KERNEL<real, K_, 256>), dim3(BATCH), dim3(256), 0, STREAM, A); \
+    else if (n__ <= K_ * 512) hipLaunchKernelGGL((KERNEL<real, K_, 512>), dim3(BATCH), dim3(512), 0, STREAM, A); \
+    else hipLaunchKernelGGL((KERNEL<real, K_, 1024>), dim3(BATCH), dim3(1024), 0, STREAM, A);                   \
+  } while (0)
+
 #define BCN_DISPATCH_1D(KERNEL, A, BATCH, STREAM)                                              \
   do {                                                                                         \
-    const int n__ = (A).n;                                                                     \
-    if (n__ <= 4 * 64) hipLaunchKernelGGL((KERNEL<real, 4, 64>), dim3(BATCH), dim3(64), 0, STREAM, A);          \
-    else if (n__ <= 8 * 64) hipLaunchKernelGGL((KERNEL<real, 8, 64>), dim3(BATCH), dim3(64), 0, STREAM, A);     \
-    else if (n__ <= 8 * 128) hipLaunchKernelGGL((KERNEL<real, 8, 128>), dim3(BATCH), dim3(128), 0, STREAM, A);  \
-    else if (n__ <= 8 * 256) hipLaunchKernelGGL((KERNEL<real, 8, 256>), dim3(BATCH), dim3(256), 0, STREAM, A);  \
-    else if (n__ <= 8 * 512) hipLaunchKernelGGL((KERNEL<real, 8, 512>), dim3(BATCH), dim3(512), 0, STREAM, A);  \
-    else if (n__ <= 8 * 1024) hipLaunchKernelGGL((KERNEL<real, 8, 1024>), dim3(BATCH), dim3(1024), 0, STREAM, A); \
-    else { bcn_set_error("1D grid of %d cells exceeds the 8192-cell kernel limit", n__); return BCN_ERR_UNSUPPORTED; } \
+    if ((A).n > 8 * 1024) {                                                                    \
+      bcn_set_error("1D grid of %d cells exceeds the 8192-cell kernel limit", (A).n);          \
+      return BCN_ERR_UNSUPPORTED;                                                              \
+    }                                                                                          \
+    int k__ = pick_k((A).n, BATCH);                                                            \
+    while ((A).n > k__ * 1024) k__ *= 2;                                                       \
+    switch (k__) {                                                                             \
+      case 1: BCN_LAUNCH_NT(KERNEL, 1, A, BATCH, STREAM); break;                               \
+      case 2: BCN_LAUNCH_NT(KERNEL, 2, A, BATCH, STREAM); break;                               \
+      case 4: BCN_LAUNCH_NT(KERNEL, 4, A, BATCH, STREAM); break;                               \
+      default: BCN_LAUNCH_NT(KERNEL, 8, A, BATCH, STREAM); break;                              \
+    }                                                                                          \
     BCN_HIP(hipGetLastError());                                                                \
   } while (0)
 
