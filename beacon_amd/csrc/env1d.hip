@@ -186,8 +186,8 @@ template <typename real, int K, int NT>
 __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
   if (A.mask && !A.mask[blockIdx.x]) return;
   constexpr int NB = (4 * NT * K * sizeof(real) <= 65536) ? 2 : 1;
-  __shared__ real lh[NB][NT * K];
-  __shared__ real lq[NB][NT * K];
+  __shared__ real lh[NB][NT * K + 1];   // + 1: a slot holding 1 for reads outside the array
+  __shared__ real lq[NB][NT * K + 1];
   __shared__ real red[NT / BCN_WAVE];
   __shared__ real s_u[64], s_up[64];
   const int b = blockIdx.x, tid = threadIdx.x, i0 = tid * K, n = A.n;
@@ -215,7 +215,30 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
   }
   const real* nz = A.noise ? A.noise + (size_t)b * A.ndt_act : nullptr;
   const real rdx3 = real(1) / (A.dx * A.dx * A.dx);
-  const int jet0 = A.jet_pos - A.jet_hw;
+  __syncthreads();   // s_u / s_up
+  // ---- everything that does not change over the action step is resolved once ----------------
+  // halo cells i0-2, i0-1, i0+K, i0+K+1, i0+K+2: LDS index with the outflow copy BC
+  // h[nx-1] = h[nx-2], q[nx-1] = q[nx-2] (shkadov.py:206-207) resolved on read; cells outside the
+  // array read a slot that holds 1 (never used by a cell that is updated)
+  constexpr int ONE = NT * K;
+  auto hidx = [&](int c) -> int { return (c < 0 || c >= n) ? ONE : (c == n - 1 ? n - 2 : c); };
+  const int xm2 = hidx(i0 - 2), xm1 = hidx(i0 - 1), xp0 = hidx(i0 + K), xp1 = hidx(i0 + K + 1), xp2 = hidx(i0 + K + 2);
+  const bool has_last = (i0 <= n - 1) && (n - 1 < i0 + K);   // this thread owns cell nx-1
+  const bool has_tail = (i0 + K > n - 3) && (i0 <= n - 2);   // ... cells nx-3 / nx-2 (one-sided d3o2u)
+  // jets (:223-232): parabolic profile on [s, e], s = jet_pos + j*space - hw, e = s + 2 hw
+  real jvv[K], ju0[K], ju1[K];
+  bool jon[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int rel = i0 + k - (A.jet_pos - A.jet_hw);
+    const int j = rel >= 0 ? rel / A.jet_space : 0;
+    const int ks = rel - j * A.jet_space;              // k - s
+    jon[k] = rel >= 0 && j < A.n_jets && ks <= 2 * A.jet_hw;
+    jvv[k] = (real)(ks * (2 * A.jet_hw - ks)) / (real(0.25) * (real)(4 * A.jet_hw * A.jet_hw));
+    ju0[k] = jon[k] ? s_up[j] : real(0);
+    ju1[k] = jon[k] ? s_u[j] : real(0);
+  }
+  if (tid == 0) { lh[0][ONE] = 1; lq[0][ONE] = 1; lh[NB - 1][ONE] = 1; lq[NB - 1][ONE] = 1; }
 
   for (int it = 0; it < A.ndt_act; it++) {
     real* Lh = lh[it & (NB - 1)];
@@ -227,21 +250,22 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
 #pragma unroll
     for (int k = 0; k < K; k++) { Lh[i0 + k] = h[k]; Lq[i0 + k] = q[k]; }
     __syncthreads();
-    // outflow copy BC h[nx-1]=h[nx-2], q[nx-1]=q[nx-2] (:206-207): resolved on read
-    auto geth = [&](int c) -> real { return (c < 0 || c >= n) ? real(1) : Lh[c == n - 1 ? n - 2 : c]; };
-    auto getq = [&](int c) -> real { return (c < 0 || c >= n) ? real(1) : Lq[c == n - 1 ? n - 2 : c]; };
     real eh[K + 5];  // cells i0-2 .. i0+K+2
     real eq[K + 3];  // cells i0-2 .. i0+K
-    eh[0] = geth(i0 - 2); eh[1] = geth(i0 - 1);
-    eq[0] = getq(i0 - 2); eq[1] = getq(i0 - 1);
+    eh[0] = Lh[xm2]; eh[1] = Lh[xm1];
+    eq[0] = Lq[xm2]; eq[1] = Lq[xm1];
+    if (has_last) {
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (i0 + k == n - 1) { h[k] = Lh[n - 2]; q[k] = Lq[n - 2]; }
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      if (i0 + k == n - 1) { h[k] = Lh[n - 2]; q[k] = Lq[n - 2]; }
       eh[k + 2] = h[k];
       eq[k + 2] = q[k];
     }
-    eh[K + 2] = geth(i0 + K); eh[K + 3] = geth(i0 + K + 1); eh[K + 4] = geth(i0 + K + 2);
-    eq[K + 2] = getq(i0 + K);
+    eh[K + 2] = Lh[xp0]; eh[K + 3] = Lh[xp1]; eh[K + 4] = Lh[xp2];
+    eq[K + 2] = Lq[xp0];
     real e2[K + 3];  // q^2/(h+eps) at cells i0-2 .. i0+K (:213)
 #pragma unroll
     for (int k = 0; k < K + 3; k++) e2[k] = fdiv<real>(eq[k] * eq[k], eh[k] + A.eps);
@@ -256,6 +280,20 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
       pq[k] = edge ? real(0) : np_clip01(r1);
       p2[k] = edge ? real(0) : np_clip01(r2);
     }
+    // d3o2u(h) (:485-491); eh index of cell c is k+2; the last two interior cells are one-sided
+    real d3[K];
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      d3[k] = (-eh[k + 5] + real(6) * eh[k + 4] - real(12) * eh[k + 3] + real(10) * eh[k + 2] -
+               real(3) * eh[k + 1]) * (real(0.5) * rdx3);
+    if (has_tail) {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int c = i0 + k;
+        if (c == n - 3) d3[k] = (eh[k + 4] - real(3) * eh[k + 3] + real(3) * eh[k + 2] - eh[k + 1]) * rdx3;
+        if (c == n - 2) d3[k] = (-eh[k] + real(3) * eh[k + 1] - real(3) * eh[k + 2] + eh[k + 3]) * rdx3;
+      }
+    }
     const real alpha = fmin((real)it / (real)A.n_interp, real(1));
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -264,32 +302,15 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
       // d1tvd(q) -> rhsh, d1tvd(q2h) -> dq2h (:494-504)
       real dq = eq[k + 2] + real(0.5) * pq[k + 1] * (eq[k + 3] - eq[k + 2]);
       dq -= eq[k + 1] + real(0.5) * pq[k] * (eq[k + 2] - eq[k + 1]);
-      dq /= A.dx;
+      dq = divc<real>(dq, A.dx, A.rdx);
       real d2 = e2[k + 2] + real(0.5) * p2[k + 1] * (e2[k + 3] - e2[k + 2]);
       d2 -= e2[k + 1] + real(0.5) * p2[k] * (e2[k + 2] - e2[k + 1]);
-      d2 /= A.dx;
-      // d3o2u(h) (:485-491); eh index of cell c is k+2
-      real d3;
-      if (c == n - 3)
-        d3 = (eh[k + 4] - real(3) * eh[k + 3] + real(3) * eh[k + 2] - eh[k + 1]) * rdx3;
-      else if (c == n - 2)
-        d3 = (-eh[k] + real(3) * eh[k + 1] - real(3) * eh[k + 2] + eh[k + 3]) * rdx3;
-      else
-        d3 = (-eh[k + 5] + real(6) * eh[k + 4] - real(12) * eh[k + 3] + real(10) * eh[k + 2] -
-              real(3) * eh[k + 1]) * (real(0.5) * rdx3);
+      d2 = divc<real>(d2, A.dx, A.rdx);
       // rhsq (:507-512)
-      real rqn = real(1.2) * d2 - A.delta_p * (h[k] * (d3 + real(1)) - fdiv<real>(q[k], h[k] * h[k] + A.eps));
-      // jets (:223-232): parabolic profile on [s, e], s = jet_pos + j*space - hw, e = s + 2 hw
-      const int rel = c - jet0;
-      if (rel >= 0) {
-        const int j = rel / A.jet_space;
-        const int ks = rel - j * A.jet_space;          // k - s
-        if (j < A.n_jets && ks <= 2 * A.jet_hw) {
-          const real uj = (real(1) - alpha) * s_up[j] + alpha * s_u[j];
-          const real vv = (real)(ks * (2 * A.jet_hw - ks)) / (real(0.25) * (real)(4 * A.jet_hw * A.jet_hw));
-          rqn += A.jet_amp * uj * vv;
-        }
-      }
+      real rqn = real(1.2) * d2 - A.delta_p * (h[k] * (d3[k] + real(1)) - fdiv<real>(q[k], h[k] * h[k] + A.eps));
+      const real uj = (real(1) - alpha) * ju0[k] + alpha * ju1[k];
+      const real rqj = rqn + A.jet_amp * uj * jvv[k];
+      rqn = jon[k] ? rqj : rqn;
       if (c >= 1 && c <= n - 2) {
         rh[k] = dq;
         rq[k] = rqn;
