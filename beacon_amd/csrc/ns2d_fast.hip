@@ -34,6 +34,14 @@
 #define BCN_LAG 0   // lagged convergence test: measured no faster (1556 vs 1555 cycles per sweep), kept for reference
 #endif
 
+#ifndef BCN_ERRB
+#define BCN_ERRB 1   // error norm across the workgroup: wave DPP reduction -> NW partials in LDS, then
+                     // 1: every lane reads them by broadcast and adds them (1 238 cycles per sweep at 128x64);
+                     // 0: DPP row reduction of one partial per lane (1 328).  Tried and dropped: no reduction in
+                     // front of the barrier, every lane publishes its partial and every wave adds the NW rows
+                     // lane-wise afterwards (1 439: 16 KB of LDS reads per sweep).
+#endif
+
 namespace {
 
 using namespace bcn_dpp;
@@ -49,10 +57,11 @@ struct FastGeom {
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY + 16;  // +16: lanes >= NY read (never write) past the array
   static constexpr int PD = 4;             // transport prefetch depth (diagonals)
-  // LDS map (elements): [ exchange 2*NW*2*64 | errp 32 | sact 64 | red 32 | .. FRONT ) U V T [ BACK )
+  // LDS map (elements): [ exchange 2*NW*3*64 | errp 32 | sact 64 | red 32 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
-  static constexpr int MISC = 2 * NW * 2 * 64 + 128 + 16;   // + 16: scheduler words (ns2d_fast_sched)
+  static constexpr int EXCH = 2 * NW * 2 * 64;              // [2 buffers][NW][west edge | east edge][64]
+  static constexpr int MISC = EXCH + 128 + 16;              // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + PD + 1) * SY;
   static constexpr size_t lds_elems() { return (size_t)FRONT + 3 * (size_t)SZ + BACK; }
@@ -128,7 +137,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
   using G = FastGeom<NX, NY, R>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
   real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
-  real* errp = exch + 2 * NW * 2 * 64;         // [2][16]
+  real* errp = exch + G::EXCH;                 // [2][16]
   real* sact = errp + 32;                      // [64]
   real* red = sact + 64;                       // [32]
   real* Ul = exch + G::FRONT;
@@ -388,9 +397,6 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #ifndef BCN_EXP
 #define BCN_EXP 0   // timing experiments only (wrong results): 1 fixed 100 sweeps, 2 no barrier, 4 no LDS exchange, 8 no reduction
 #endif
-#ifndef BCN_ERRB
-#define BCN_ERRB 1   // 1: broadcast-read the NW error partials and add them per lane; 0: DPP row reduction
-#endif
     real eB[NW];
 #define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                        \
     {                                                                                        \
@@ -402,6 +408,9 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
         DST[k] = ph;                                                                         \
       }                                                                                      \
       const real pI = wl * acc;   /* the edge cells join below: short tail in front of the barrier */ \
+      /* keep the halo-dependent part behind the interior cells: hipcc otherwise sometimes hoists the  \
+         edge cells (and their s_waitcnt on the LDS reads) in front of them: +170 cycles per sweep */   \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
       if (itp > 0) {                                                                         \
         real err;                                                                            \
         if (BCN_ERRB) {   /* every lane sums the NW partials it read by broadcast */         \
@@ -564,7 +573,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
-                                                          2 * FastGeom<NX, NY, R>::NW * 2 * 64 + 128);
+                                                          FastGeom<NX, NY, R>::EXCH + 128);
   ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
     fast_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
   });
