@@ -347,6 +347,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         BCN_CELL(DST, SRC, k, e, w)                                                                  \
       }                                                                                              \
       const real pI = wl0 * acc0 + wl1 * acc1;   /* the edge columns join below: short tail */        \
+      __builtin_amdgcn_sched_barrier(0);   /* halo-dependent part stays behind the interior cells */ \
       if (itp > 0) {                                                                                 \
         real err;                                                                                    \
         if (BCN2_ERRB) { /* every lane adds the NW partials it read by broadcast */                  \
