@@ -255,6 +255,57 @@ def test_rayleigh_100x100_fast2_vs_oracle_and_generic():
     env.close()
 
 
+def test_ns2d_generic_other_grids_vs_oracle_f64():
+    """The generic kernel on grids no fast path covers (non-square cells of the domain, other segment
+    counts, dx != dy is not reachable through the reference's constructors): rayleigh L=3, H=1 ->
+    150x50 with 5 segments and Ra=5e3, mixing L=1, H=2 -> 100x200; float64 against the oracle."""
+    rng = np.random.default_rng(11)
+    nx, ny = 150, 50
+    x, y = (np.arange(nx + 2) - 0.5) / nx, (np.arange(ny + 2) - 0.5) / ny
+    init = np.zeros((4, nx + 2, ny + 2))
+    init[3] = (0.5 - y)[None, :] + 0.1 * np.sin(6 * np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]
+    B, NDT = 3, 4
+    acts = rng.uniform(-1, 1, (2, B, 5))
+    env = V.VecRayleigh(B, DEV, "f64", init, L=3.0, H=1.0, n_sgts=5, ra=5.0e3)
+    env.set_ndt_act(NDT)
+    env.reset()
+    oracles = [O.rayleigh(init_fields=init, L=3.0, H=1.0, n_sgts=5, ra=5.0e3) for _ in range(B)]
+    for o in oracles:
+        o.cfg.ndt_act = NDT
+        o.reset()
+    for k in range(2):
+        obs, rwd, _, _, _ = env.step(acts[k])
+        env.check_status()
+        assert env.kernel_name == "ns2d_generic_step"
+        st, sw = dev2ref(env.get_state()), env.sweeps.cpu().numpy()
+        for b, o in enumerate(oracles):
+            ob, rw, _, _, _ = o.step(acts[k, b].tolist())
+            for i, F in enumerate("uvpT"):
+                assert maxdiff(st[b][i], o.st[i]) <= F64_TOL * (50 if F == "p" else 1), (k, b, F)
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and abs(float(rwd[b]) - rw) <= 1e-8
+            assert np.max(np.abs(sw[b] - o.itp)) <= 1
+    env.close()
+
+    env = V.VecMixing(2, DEV, "f64", L=1.0, H=2.0)
+    env.set_ndt_act(2)
+    env.reset()
+    oracles = [O.mixing(L=1.0, H=2.0) for _ in range(2)]
+    for o in oracles:
+        o.cfg.ndt_act = 2
+        o.reset()
+    a = np.array([0, 2])
+    obs, rwd, _, _, _ = env.step(a)
+    env.check_status()
+    st, sw = dev2ref(env.get_state()), env.sweeps.cpu().numpy()
+    for b, o in enumerate(oracles):
+        ob, rw, _, _, _ = o.step(int(a[b]))
+        for i, F in enumerate("uvpC"):
+            assert maxdiff(st[b][i], o.st[i]) <= F64_TOL * (50 if F == "p" else 1), (b, F)
+        assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and abs(float(rwd[b]) - rw) <= 1e-9
+        assert np.max(np.abs(sw[b] - o.itp)) <= 1
+    env.close()
+
+
 def test_rayleigh_episode_end_and_overflow():
     g = golden("rayleigh_default")
     env = V.VecRayleigh(2, DEV, "f64", _ray_init(g))
