@@ -34,7 +34,7 @@ struct NS2DEnv : bcn_env_s {
   NS2DArgs<real> a{};
   DevBuf fields;    // u,v,p,S,us,vs   [6][B][ncell]
   DevBuf work;      // g0,g1,g2        [3][B][ncell]  (only when the work arrays do not fit LDS)
-  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf, schedbuf;
+  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf, schedbuf, fscrbuf;
   bool fast_ok = false;
 
   int init() {
@@ -71,12 +71,17 @@ struct NS2DEnv : bcn_env_s {
     if ((rc = schedbuf.alloc(128 + (size_t)batch * sizeof(uint32_t)))) return rc;
     a.sched_ctl = schedbuf.p;
     fast_ok = ns2d_fast_supported<real>(a);
+    if (fast_ok && (a.fscr_stride = ns2d_fast_scratch_elems<real>(a)) > 0) {
+      if ((rc = fscrbuf.alloc((size_t)batch * a.fscr_stride * sizeof(real)))) return rc;
+      BCN_HIP(hipMemset(fscrbuf.p, 0, fscrbuf.bytes));
+      a.fscr = static_cast<real*>(fscrbuf.p);
+    }
     variant = fast_ok ? 1 : 0;
     return BCN_OK;
   }
   ~NS2DEnv() override {
     DeviceGuard g(device);
-    fields.release(); work.release(); obs_hist.release(); a_last.release(); ia_last.release();
+    fields.release(); work.release(); fscrbuf.release(); obs_hist.release(); a_last.release(); ia_last.release();
     stpbuf.release(); sweepbuf.release(); orderbuf.release(); schedbuf.release();
   }
   size_t state_elems() const override { return 4 * (size_t)a.ncell; }

@@ -50,6 +50,8 @@ struct NS2DArgs {
   void* sched_ctl;          // handle-owned control block of the ticketed chunk scheduler (64 + 4B bytes)
   int sched_q;              // timesteps per chunk
   const char** launched;    // host side: receives the name of the kernel the launcher dispatched (may be NULL)
+  real* fscr;               // per-workgroup field scratch of the register-resident kernels whose u, v, T do not
+  size_t fscr_stride;       //   fit LDS (float64 128x64): [slots][fscr_stride] elements, slot = workgroup index
 };
 
 // launchers (one per translation unit)
@@ -60,5 +62,7 @@ size_t ns2d_generic_lds_bytes(int ncell, size_t esz);
 template <typename real> bool ns2d_fast_supported(const NS2DArgs<real>& a);
 template <typename real> int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s);
 // two-rows-per-lane variant for 64 < ny <= 128 (ns2d_fast2.hip), reached through ns2d_launch_fast
+// elements of field scratch one workgroup of the fast path needs for this configuration (0: fields live in LDS)
+template <typename real> size_t ns2d_fast_scratch_elems(const NS2DArgs<real>& a);
 template <typename real> bool ns2d_fast2_supported(const NS2DArgs<real>& a);
 template <typename real> int ns2d_launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s);

@@ -30,6 +30,12 @@
 #ifndef BCN_R128
 #define BCN_R128 16
 #endif
+#ifndef BCN_PDG
+#define BCN_PDG 4    // deeper (16, 32) costs registers in the out-of-line chain and slows the whole kernel
+#endif
+#ifndef BCN_R128D
+#define BCN_R128D 16   // columns per lane of the float64 128x64 kernel
+#endif
 #ifndef BCN_LAG
 #define BCN_LAG 0   // lagged convergence test: measured no faster (1556 vs 1555 cycles per sweep), kept for reference
 #endif
@@ -46,7 +52,9 @@ namespace {
 
 using namespace bcn_dpp;
 
-template <int NX, int NY, int R>
+// GF ("global fields"): u, v, T (with the same pads) live in a per-workgroup global scratch instead of LDS
+// (float64 at 128x64: 3 x 68.6 KB do not fit); LDS then holds only the exchange buffers.
+template <int NX, int NY, int R, bool GF = false>
 struct FastGeom {
   static_assert(NX % R == 0, "strip width must divide nx");
   static_assert(NY <= 64, "lanes run along y");
@@ -56,7 +64,7 @@ struct FastGeom {
   static constexpr int SY = NY + 2;
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY + 16;  // +16: lanes >= NY read (never write) past the array
-  static constexpr int PD = 4;             // transport prefetch depth (diagonals)
+  static constexpr int PD = GF ? BCN_PDG : 4;   // transport prefetch depth (diagonals); deeper for global fields
   // LDS map (elements): [ exchange 2*NW*3*64 | errp 32 | sact 64 | red 32 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
@@ -64,15 +72,17 @@ struct FastGeom {
   static constexpr int MISC = EXCH + 128 + 16;              // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + PD + 1) * SY;
-  static constexpr size_t lds_elems() { return (size_t)FRONT + 3 * (size_t)SZ + BACK; }
+  static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
+  static constexpr size_t lds_elems() { return GF ? (size_t)(MISC + 15) / 16 * 16 : (size_t)FRONT + 3 * (size_t)SZ + BACK; }
+  static constexpr size_t scratch_elems() { return GF ? (size_t)FRONTG + 3 * (size_t)SZ + BACK : 0; }
 };
 
 // Ordered part of the transport step, run by ONE wave (kept out of line: its unrolled,
 // software-pipelined loops would otherwise inflate the register pressure of the whole kernel).
-template <typename real, int NX, int NY, int R>
+template <typename real, int NX, int NY, int R, bool GF>
 __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* Ul, const real* Vl, real* dummy,
                                                           real c0x, real c1x, real c0y, real c1y) {
-  using G = FastGeom<NX, NY, R>;
+  using G = FastGeom<NX, NY, R, GF>;
   constexpr int SY = G::SY, PD = G::PD;
   const int lane = threadIdx.x & 63;
   const int j = lane + 1;
@@ -131,16 +141,16 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
     }
 
 // One unit of work: timesteps [it_begin, it_end) of replica b (state HBM -> chip -> HBM).
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
 __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
                                           const bool first_chunk, const bool last_chunk, char* smem) {
-  using G = FastGeom<NX, NY, R>;
+  using G = FastGeom<NX, NY, R, GF>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
   real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
   real* errp = exch + G::EXCH;                 // [2][16]
   real* sact = errp + 32;                      // [64]
   real* red = sact + 64;                       // [32]
-  real* Ul = exch + G::FRONT;
+  real* Ul = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride + G::FRONTG : exch + G::FRONT;
   real* Vl = Ul + SZ;
   real* Tl = Vl + SZ;
 
@@ -514,7 +524,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     BCN_PH(4)
     // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
     if (w == 0) {
-      transport_chain<real, NX, NY, R>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+      transport_chain<real, NX, NY, R, GF>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
                                        dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     }
     __syncthreads();
@@ -559,23 +569,23 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 }
 
 // plain launch: one workgroup per replica, timesteps [A.it_begin, A.it_end)
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
 __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
   if (A.mask && !A.mask[b]) return;
-  fast_unit<real, NX, NY, R, KIND, EQ>(A, b, A.it_begin, A.it_end, A.first_chunk != 0, A.last_chunk != 0, smem);
+  fast_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, A.it_begin, A.it_end, A.first_chunk != 0, A.last_chunk != 0, smem);
 }
 
 // ---- ticketed chunk scheduler (ns2d_sched.h) ---------------------------------------------------
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
 __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
-                                                          FastGeom<NX, NY, R>::EXCH + 128);
+                                                          FastGeom<NX, NY, R, GF>::EXCH + 128);
   ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
-    fast_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
+    fast_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, it0, it1, first, last, smem);
   });
 }
 
@@ -603,11 +613,12 @@ __global__ __launch_bounds__(1024) void ns2d_rank_by_work(const int32_t* sweeps,
   }
 }
 
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
 int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
-  using G = FastGeom<NX, NY, R>;
+  using G = FastGeom<NX, NY, R, GF>;
+  if (GF && (!a.fscr || a.fscr_stride < G::scratch_elems())) { bcn_set_error("fast path: field scratch missing"); return BCN_ERR_UNSUPPORTED; }
   const size_t lds = G::lds_elems() * sizeof(real);
-  auto k = ns2d_fast_step<real, NX, NY, R, KIND, EQ>;
+  auto k = ns2d_fast_step<real, NX, NY, R, KIND, EQ, GF>;
   static bool attr_set = false;
   if (!attr_set) {
     BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -618,7 +629,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   const SchedParams& sp = ns2d_sched_params();
   const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
-    auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ>;
+    auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ, GF>;
     static bool attr_set2 = false;
     if (!attr_set2) {
       BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -660,11 +671,11 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   return BCN_OK;
 }
 
-template <typename real, int NX, int NY, int R, int KIND>
+template <typename real, int NX, int NY, int R, int KIND, bool GF = false>
 int launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   // dx == dy (every reference configuration): one multiply per cell instead of two
-  if (a.cx == a.cy) return launch_fast_eq<real, NX, NY, R, KIND, true>(a, batch, s);
-  return launch_fast_eq<real, NX, NY, R, KIND, false>(a, batch, s);
+  if (a.cx == a.cy) return launch_fast_eq<real, NX, NY, R, KIND, true, GF>(a, batch, s);
+  return launch_fast_eq<real, NX, NY, R, KIND, false, GF>(a, batch, s);
 }
 
 template <typename real>
@@ -672,6 +683,7 @@ int fast_config(const NS2DArgs<real>& a) {
   if (a.kind != 0 || a.n_sgts > 64) return 0;
   if (a.nx == 128 && a.ny == 64 && sizeof(real) == 4) return 1;
   if (a.nx == 50 && a.ny == 50) return 2;
+  if (a.nx == 128 && a.ny == 64 && sizeof(real) == 8) return 3;   // fields in global scratch
   return 0;
 }
 
@@ -688,12 +700,22 @@ int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
       if constexpr (std::is_same<real, float>::value) return launch_fast<float, 128, 64, BCN_R128, 0>(a, batch, s);
       break;
     case 2: return launch_fast<real, 50, 50, 5, 0>(a, batch, s);
+    case 3:
+      if constexpr (std::is_same<real, double>::value) return launch_fast<double, 128, 64, BCN_R128D, 0, true>(a, batch, s);
+      break;
     default: break;
   }
   bcn_set_error("no register-resident kernel for this grid");
   return BCN_ERR_UNSUPPORTED;
 }
 
+template <typename real>
+size_t ns2d_fast_scratch_elems(const NS2DArgs<real>& a) {
+  if (fast_config<real>(a) == 3) return FastGeom<128, 64, BCN_R128D, true>::scratch_elems();
+  return 0;
+}
+template size_t ns2d_fast_scratch_elems<float>(const NS2DArgs<float>&);
+template size_t ns2d_fast_scratch_elems<double>(const NS2DArgs<double>&);
 template bool ns2d_fast_supported<float>(const NS2DArgs<float>&);
 template bool ns2d_fast_supported<double>(const NS2DArgs<double>&);
 template int ns2d_launch_fast<float>(const NS2DArgs<float>&, int, hipStream_t);

@@ -9,7 +9,7 @@ build.FLAGS.extend(["-DBCN_STAMP"] + extra); build.build_lib(force=True)
 from beacon_amd import vec as V
 z = np.load("tests/golden/rayleigh_128x64_init.npz")
 B = 512
-env = V.VecRayleigh(B, "cuda:0", "f32", z["fields"], L=2.56, H=1.28)
+env = V.VecRayleigh(B, "cuda:0", os.environ.get("BCN_STAMP_DTYPE", "f32"), z["fields"], L=2.56, H=1.28)
 env.reset()
 acts = np.random.default_rng(0).uniform(-1, 1, (3, B, 10))
 for k in range(3):
