@@ -30,6 +30,9 @@
 #ifndef BCN_R128
 #define BCN_R128 16
 #endif
+#ifndef BCN_GFD
+#define BCN_GFD 2   // float64 128x64: 1 = u, v, T in global scratch, 2 = u, v in LDS and T in global scratch
+#endif
 #ifndef BCN_PDG
 #define BCN_PDG 4    // deeper (16, 32) costs registers in the out-of-line chain and slows the whole kernel
 #endif
@@ -52,9 +55,10 @@ namespace {
 
 using namespace bcn_dpp;
 
-// GF ("global fields"): u, v, T (with the same pads) live in a per-workgroup global scratch instead of LDS
-// (float64 at 128x64: 3 x 68.6 KB do not fit); LDS then holds only the exchange buffers.
-template <int NX, int NY, int R, bool GF = false>
+// GF ("global fields", float64 at 128x64: 3 x 68.6 KB do not fit LDS): 1 = u, v, T (with the same pads) live in
+// a per-workgroup global scratch and LDS holds only the exchange buffers; 2 = u, v in LDS without pads (the
+// transport wave clamps its skewed reads instead) and only T, with its pads, in the global scratch.
+template <int NX, int NY, int R, int GF = 0>
 struct FastGeom {
   static_assert(NX % R == 0, "strip width must divide nx");
   static_assert(NY <= 64, "lanes run along y");
@@ -73,13 +77,18 @@ struct FastGeom {
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + PD + 1) * SY;
   static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
-  static constexpr size_t lds_elems() { return GF ? (size_t)(MISC + 15) / 16 * 16 : (size_t)FRONT + 3 * (size_t)SZ + BACK; }
-  static constexpr size_t scratch_elems() { return GF ? (size_t)FRONTG + 3 * (size_t)SZ + BACK : 0; }
+  static constexpr int MISCA = (MISC + 15) / 16 * 16;
+  static constexpr size_t lds_elems() {
+    return GF == 1 ? (size_t)MISCA : GF == 2 ? (size_t)MISCA + 2 * (size_t)SZ : (size_t)FRONT + 3 * (size_t)SZ + BACK;
+  }
+  static constexpr size_t scratch_elems() {
+    return GF == 1 ? (size_t)FRONTG + 3 * (size_t)SZ + BACK : GF == 2 ? (size_t)FRONTG + SZ + BACK : 0;
+  }
 };
 
 // Ordered part of the transport step, run by ONE wave (kept out of line: its unrolled,
 // software-pipelined loops would otherwise inflate the register pressure of the whole kernel).
-template <typename real, int NX, int NY, int R, bool GF>
+template <typename real, int NX, int NY, int R, int GF>
 __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* Ul, const real* Vl, real* dummy,
                                                           real c0x, real c1x, real c0y, real c1y) {
   using G = FastGeom<NX, NY, R, GF>;
@@ -94,11 +103,12 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
       // below by DPP and ignore it.  Reads are unmasked (see the LDS map), only writes are.
       const int cb = (1 - lane) * SY + j;
       real* Tb = Tl + cb;
-      const real* Ub = Ul + cb;
-      const real* Vb = Vl + cb;
+      // u, v without pads (GF == 2): lanes outside the domain read a clamped index (their values are masked)
+      auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ul[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ul[x]; };
+      auto ldv = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Vl[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Vl[x]; };
       real ra[PD], ru[PD], rv[PD], rg[PD];
 #pragma unroll
-      for (int q = 0; q < PD; q++) { ra[q] = Tb[q * SY]; ru[q] = Ub[q * SY]; rv[q] = Vb[q * SY]; rg[q] = Tb[q * SY - 1]; }
+      for (int q = 0; q < PD; q++) { ra[q] = Tb[q * SY]; ru[q] = ldu(q); rv[q] = ldv(q); rg[q] = Tb[q * SY - 1]; }
       real tp = Tl[0 * SY + j];                        // west ghost
       // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
 #define BCN_CHAIN(T0, T1, MASK)                                                             \
@@ -119,8 +129,8 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
             *dst = tn;                                                                      \
           }                                                                                 \
           ra[q] = Tb[(t + PD) * SY];                                                        \
-          ru[q] = Ub[(t + PD) * SY];                                                        \
-          rv[q] = Vb[(t + PD) * SY];                                                        \
+          ru[q] = ldu(t + PD);                                                              \
+          rv[q] = ldv(t + PD);                                                              \
           rg[q] = Tb[(t + PD) * SY - 1];                                                    \
         }                                                                                   \
       }
@@ -141,7 +151,7 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
     }
 
 // One unit of work: timesteps [it_begin, it_end) of replica b (state HBM -> chip -> HBM).
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
                                           const bool first_chunk, const bool last_chunk, char* smem) {
   using G = FastGeom<NX, NY, R, GF>;
@@ -150,9 +160,10 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
   real* errp = exch + G::EXCH;                 // [2][16]
   real* sact = errp + 32;                      // [64]
   real* red = sact + 64;                       // [32]
-  real* Ul = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride + G::FRONTG : exch + G::FRONT;
+  real* gscr = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride + G::FRONTG : nullptr;
+  real* Ul = GF == 1 ? gscr : GF == 2 ? exch + G::MISCA : exch + G::FRONT;
   real* Vl = Ul + SZ;
-  real* Tl = Vl + SZ;
+  real* Tl = GF == 2 ? gscr : Vl + SZ;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane + 1;
@@ -569,7 +580,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 }
 
 // plain launch: one workgroup per replica, timesteps [A.it_begin, A.it_end)
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
@@ -578,7 +589,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A
 }
 
 // ---- ticketed chunk scheduler (ns2d_sched.h) ---------------------------------------------------
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(1024) void ns2d_rank_by_work(const int32_t* sweeps,
   }
 }
 
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, bool GF>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   using G = FastGeom<NX, NY, R, GF>;
   if (GF && (!a.fscr || a.fscr_stride < G::scratch_elems())) { bcn_set_error("fast path: field scratch missing"); return BCN_ERR_UNSUPPORTED; }
@@ -671,7 +682,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   return BCN_OK;
 }
 
-template <typename real, int NX, int NY, int R, int KIND, bool GF = false>
+template <typename real, int NX, int NY, int R, int KIND, int GF = 0>
 int launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   // dx == dy (every reference configuration): one multiply per cell instead of two
   if (a.cx == a.cy) return launch_fast_eq<real, NX, NY, R, KIND, true, GF>(a, batch, s);
@@ -701,7 +712,7 @@ int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
       break;
     case 2: return launch_fast<real, 50, 50, 5, 0>(a, batch, s);
     case 3:
-      if constexpr (std::is_same<real, double>::value) return launch_fast<double, 128, 64, BCN_R128D, 0, true>(a, batch, s);
+      if constexpr (std::is_same<real, double>::value) return launch_fast<double, 128, 64, BCN_R128D, 0, BCN_GFD>(a, batch, s);
       break;
     default: break;
   }
@@ -711,7 +722,7 @@ int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
 
 template <typename real>
 size_t ns2d_fast_scratch_elems(const NS2DArgs<real>& a) {
-  if (fast_config<real>(a) == 3) return FastGeom<128, 64, BCN_R128D, true>::scratch_elems();
+  if (fast_config<real>(a) == 3) return FastGeom<128, 64, BCN_R128D, BCN_GFD>::scratch_elems();
   return 0;
 }
 template size_t ns2d_fast_scratch_elems<float>(const NS2DArgs<float>&);
