@@ -67,7 +67,7 @@ template <typename real, int K, int NT>
 __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
   if (A.mask && !A.mask[blockIdx.x]) return;
   constexpr int NB = (2 * NT * K * sizeof(real) <= 65536) ? 2 : 1;
-  __shared__ real lds[NB][NT * K];
+  __shared__ real lds[NB][NT * K + 1];   // + 1: a slot holding 0 for reads outside the array
   __shared__ real red[NT / BCN_WAVE];
   const int b = blockIdx.x, tid = threadIdx.x, i0 = tid * K, n = A.n;
   real* gu = A.f0 + (size_t)b * n;
@@ -85,6 +85,13 @@ __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
   const real noise = A.noise ? A.noise[b] : real(0);
   if (tid == 0) A.a_last[b] = act;
   const real force = act * A.amp;
+  // static per thread: halo indices with the outflow copy u[nx-1] = u[nx-2] (:138) resolved on read
+  // (cells outside the array read a slot holding 0: they only feed limiter entries that are masked)
+  constexpr int ZERO = NT * K;
+  auto hidx = [&](int c) -> int { return (c < 0 || c >= n) ? ZERO : (c == n - 1 ? n - 2 : c); };
+  const int xm2 = hidx(i0 - 2), xm1 = hidx(i0 - 1), xp0 = hidx(i0 + K);
+  const bool has_last = (i0 <= n - 1) && (n - 1 < i0 + K);
+  if (tid == 0) { lds[0][ZERO] = 0; lds[NB - 1][ZERO] = 0; }
 
   for (int it = 0; it < A.ndt_act; it++) {
     real* L = lds[it & (NB - 1)];
@@ -94,17 +101,17 @@ __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
 #pragma unroll
     for (int k = 0; k < K; k++) L[i0 + k] = u[k];
     __syncthreads();
-    // u[nx-1] = u[nx-2] (:138): resolved on read
-    auto get = [&](int c) -> real { return L[c == n - 1 ? n - 2 : c]; };
     real e[K + 3];  // cells i0-2 .. i0+K
-    e[0] = i0 >= 2 ? get(i0 - 2) : real(0);
-    e[1] = i0 >= 1 ? get(i0 - 1) : real(0);
+    e[0] = L[xm2];
+    e[1] = L[xm1];
+    if (has_last) {
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      if (i0 + k == n - 1) u[k] = L[n - 2];
-      e[k + 2] = u[k];
+      for (int k = 0; k < K; k++)
+        if (i0 + k == n - 1) u[k] = L[n - 2];
     }
-    e[K + 2] = (i0 + K < n) ? get(i0 + K) : real(0);
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k + 2] = u[k];
+    e[K + 2] = L[xp0];
     real ph[K + 1];  // limiter at cells i0-1 .. i0+K-1 (zero at both ends, :232-236)
 #pragma unroll
     for (int k = 0; k <= K; k++) {
@@ -377,8 +384,8 @@ template <typename real, int K, int NT>
 __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
   if (A.mask && !A.mask[blockIdx.x]) return;
   constexpr int NB = (4 * NT * K * sizeof(real) <= 65536) ? 2 : 1;
-  __shared__ real lh[NB][NT * K];
-  __shared__ real lq[NB][NT * K];
+  __shared__ real lh[NB][NT * K + 1];   // + 1: a slot holding 1 (h) / 0 (q) for reads outside the array
+  __shared__ real lq[NB][NT * K + 1];
   __shared__ real red[NT / BCN_WAVE];
   const int b = blockIdx.x, tid = threadIdx.x, i0 = tid * K, n = A.n, nx = A.nx;
   real* gh = A.f0 + (size_t)b * n;
@@ -399,6 +406,14 @@ __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
   __syncthreads();
   if (tid == 0) { A.a_last[b] = un; A.a_prev[b] = uo; }
   const real g = A.g;
+  // static per thread: halo indices with the wall BCs h[0]=h[1], q[0]=0, h[nx+1]=h[nx], q[nx+1]=0 (:184-187)
+  // resolved on read
+  constexpr int SLOT = NT * K;
+  auto hh = [&](int c) -> int { return (c < 0 || c >= n) ? SLOT : (c == 0 ? 1 : (c == n - 1 ? n - 2 : c)); };
+  auto hq = [&](int c) -> int { return (c <= 0 || c >= n - 1) ? SLOT : c; };
+  const int xhm = hh(i0 - 1), xhp = hh(i0 + K), xqm = hq(i0 - 1), xqp = hq(i0 + K);
+  const bool has_wall = (i0 == 0) || ((i0 <= n - 1) && (n - 1 < i0 + K));
+  if (tid == 0) { lh[0][SLOT] = 1; lh[NB - 1][SLOT] = 1; lq[0][SLOT] = 0; lq[NB - 1][SLOT] = 0; }
 
   for (int it = 0; it < A.ndt_act; it++) {
     real* Lh = lh[it & (NB - 1)];
@@ -406,25 +421,21 @@ __global__ __launch_bounds__(NT) void sloshing_step_k(Env1DArgs<real> A) {
 #pragma unroll
     for (int k = 0; k < K; k++) { Lh[i0 + k] = h[k]; Lq[i0 + k] = q[k]; }
     __syncthreads();
-    // wall BCs h[0]=h[1], q[0]=0, h[nx+1]=h[nx], q[nx+1]=0 (:184-187): resolved on read
-    auto geth = [&](int c) -> real {
-      if (c < 0 || c >= n) return real(1);
-      return Lh[c == 0 ? 1 : (c == n - 1 ? n - 2 : c)];
-    };
-    auto getq = [&](int c) -> real {
-      if (c <= 0 || c >= n - 1) return real(0);
-      return Lq[c];
-    };
     real eh[K + 2], eq[K + 2];  // cells i0-1 .. i0+K
-    eh[0] = geth(i0 - 1); eq[0] = getq(i0 - 1);
+    eh[0] = Lh[xhm]; eq[0] = Lq[xqm];
+    if (has_wall) {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const int c = i0 + k;
+        if (c == 0 || c == n - 1) { h[k] = Lh[c == 0 ? 1 : n - 2]; q[k] = real(0); }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      const int c = i0 + k;
-      if (c == 0 || c == n - 1) { h[k] = geth(c); q[k] = real(0); }
       eh[k + 1] = h[k];
       eq[k + 1] = q[k];
     }
-    eh[K + 1] = geth(i0 + K); eq[K + 1] = getq(i0 + K);
+    eh[K + 1] = Lh[xhp]; eq[K + 1] = Lq[xqp];
     real ev[K + 2], eg[K + 2], es[K + 2];  // v, q^2/h + g h^2/2, |v| + sqrt(g h) (:193-199)
 #pragma unroll
     for (int k = 0; k < K + 2; k++) {
