@@ -24,10 +24,10 @@ __device__ __forceinline__ real np_max(real a, real b) {
   return (a > b || a != a) ? a : b;
 }
 
-// float32 kernels: divisions outside burgers' limiter and BDF2 update use a * v_rcp_f32(b) (~1.5 ulp,
-// operands are O(1): no denormal scaling needed) and 1/dx is a multiplication; IEEE division costs ~10
-// VALU instructions and made up 20-30 % of the step time (scripts/exp_1ddiv.sh).  float64 keeps the
-// reference's divisions.
+// float32 kernels: divisions use a * v_rcp_f32(b) (~1.5 ulp, operands are O(1): no denormal scaling
+// needed) and 1/dx is a multiplication; IEEE division costs ~10 VALU instructions and made up 20-40 % of
+// the step time (scripts/exp_1ddiv.sh).  One exception: burgers' BDF2 update keeps the true division by 3
+// (a reciprocal constant is a systematic bias there).  float64 keeps the reference's divisions.
 template <typename real> __device__ __forceinline__ real fdiv(real a, real b) { return a / b; }
 template <> __device__ __forceinline__ float fdiv<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 template <typename real> __device__ __forceinline__ real divc(real a, real c, real rc) { (void)rc; return a / c; }
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(NT) void burgers_step_k(Env1DArgs<real> A) {
 #pragma unroll
     for (int k = 0; k <= K; k++) {
       const int c = i0 - 1 + k;
-      real r = (e[k + 1] - e[k]) / (e[k + 2] - e[k + 1] + real(1.0e-8));
-      real f = (r + bcn_abs(r)) / (real(1) + r);
+      real r = fdiv<real>(e[k + 1] - e[k], e[k + 2] - e[k + 1] + real(1.0e-8));
+      real f = fdiv<real>(r + bcn_abs(r), real(1) + r);
       ph[k] = (c <= 0 || c >= n - 1) ? real(0) : f;
     }
 #pragma unroll
