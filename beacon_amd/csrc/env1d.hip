@@ -8,6 +8,8 @@
 // /root/reference/beacon/.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "env1d.h"
 
 namespace {
@@ -247,10 +249,20 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
   }
   if (tid == 0) { lh[0][ONE] = 1; lq[0][ONE] = 1; lh[NB - 1][ONE] = 1; lq[NB - 1][ONE] = 1; }
 
-  for (int it = 0; it < A.ndt_act; it++) {
+  // Waves whose cells are all away from both ends of the array (all but the first and the last one on the
+  // reference grids) run a body without edge cases; waves without jet cells skip the forcing.  Both flags are
+  // wave-uniform, every variant executes the one barrier of the timestep.
+  const bool t_int = (i0 >= 2) && (i0 + K + 2 <= n - 2);
+  bool t_jet = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) t_jet = t_jet || jon[k];
+  const bool w_int = __builtin_amdgcn_ballot_w64(!t_int) == 0;
+  const bool w_jet = __builtin_amdgcn_ballot_w64(t_jet) != 0;
+  auto step = [&](const int it, auto int_tag, auto jet_tag) {
+    constexpr bool INT = decltype(int_tag)::value, JET = decltype(jet_tag)::value;
     real* Lh = lh[it & (NB - 1)];
     real* Lq = lq[it & (NB - 1)];
-    if (tid == 0) {                                   // inlet BC (:204-205)
+    if (!INT && tid == 0) {                           // inlet BC (:204-205)
       h[0] = real(1) + (nz ? nz[it] : real(0));
       q[0] = real(1);
     }
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
     real eq[K + 3];  // cells i0-2 .. i0+K
     eh[0] = Lh[xm2]; eh[1] = Lh[xm1];
     eq[0] = Lq[xm2]; eq[1] = Lq[xm1];
-    if (has_last) {
+    if (!INT && has_last) {
 #pragma unroll
       for (int k = 0; k < K; k++)
         if (i0 + k == n - 1) { h[k] = Lh[n - 2]; q[k] = Lq[n - 2]; }
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
 #pragma unroll
     for (int k = 0; k <= K; k++) {
       const int c = i0 - 1 + k;
-      const bool edge = (c <= 0 || c >= n - 1);
+      const bool edge = !INT && (c <= 0 || c >= n - 1);
       real r1 = fdiv<real>(eq[k + 1] - eq[k], eq[k + 2] - eq[k + 1] + real(1.0e-8));
       real r2 = fdiv<real>(e2[k + 1] - e2[k], e2[k + 2] - e2[k + 1] + real(1.0e-8));
       pq[k] = edge ? real(0) : np_clip01(r1);
@@ -293,7 +305,7 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
     for (int k = 0; k < K; k++)
       d3[k] = (-eh[k + 5] + real(6) * eh[k + 4] - real(12) * eh[k + 3] + real(10) * eh[k + 2] -
                real(3) * eh[k + 1]) * (real(0.5) * rdx3);
-    if (has_tail) {
+    if (!INT && has_tail) {
 #pragma unroll
       for (int k = 0; k < K; k++) {
         const int c = i0 + k;
@@ -315,10 +327,12 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
       d2 = divc<real>(d2, A.dx, A.rdx);
       // rhsq (:507-512)
       real rqn = real(1.2) * d2 - A.delta_p * (h[k] * (d3[k] + real(1)) - fdiv<real>(q[k], h[k] * h[k] + A.eps));
-      const real uj = (real(1) - alpha) * ju0[k] + alpha * ju1[k];
-      const real rqj = rqn + A.jet_amp * uj * jvv[k];
-      rqn = jon[k] ? rqj : rqn;
-      if (c >= 1 && c <= n - 2) {
+      if (JET) {
+        const real uj = (real(1) - alpha) * ju0[k] + alpha * ju1[k];
+        const real rqj = rqn + A.jet_amp * uj * jvv[k];
+        rqn = jon[k] ? rqj : rqn;
+      }
+      if (INT || (c >= 1 && c <= n - 2)) {
         rh[k] = dq;
         rq[k] = rqn;
         h[k] += real(0.5) * A.dt * (real(-3) * dq + rhp);    // adams (:515-518)
@@ -326,6 +340,12 @@ __global__ __launch_bounds__(NT) void shkadov_step_k(Env1DArgs<real> A) {
       }
     }
     if (NB == 1) __syncthreads();
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  for (int it = 0; it < A.ndt_act; it++) {
+    if (w_int) { if (w_jet) step(it, T_{}, T_{}); else step(it, T_{}, F_{}); }
+    else { if (w_jet) step(it, F_{}, T_{}); else step(it, F_{}, F_{}); }
   }
 #pragma unroll
   for (int k = 0; k < K; k++) {
