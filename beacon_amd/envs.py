@@ -39,8 +39,13 @@ class _Single(object):
     def _episode(self):
         return bool(self.vec.done[0].item()), bool(self.vec.trunc[0].item())
 
+    stp_plot = 0        # frames written since the last reset (rayleigh.py:128, ...)
+    _render = None      # function of beacon_amd.render
+
     def render(self, mode="human", show=False, dump=True):
-        raise NotImplementedError("render() is host-side visualisation, out of scope (SURVEY.md 2.1 #9)")
+        """Host-side frame + text dumps in the reference's render/ layout (beacon_amd/render.py)."""
+        from . import render as R
+        getattr(R, self._render)(self, show, dump)
 
     def close(self):
         self.vec.close()
@@ -57,6 +62,7 @@ def _fields_2d(state):
 
 
 class rayleigh(_Single):
+    _render = "rayleigh"
     """rayleigh/rayleigh.py:16-366"""
 
     def __init__(self, cpu=0, init=True, L=1.0, H=1.0, n_sgts=10, ra=1.0e4, device="cuda:0", dtype="f64"):
@@ -72,10 +78,13 @@ class rayleigh(_Single):
                   "ny_obs_pts", "n_obs_steps", "action_space", "observation_space"):
             setattr(self, k, getattr(v, k))
         self.a = [0.0] * n_sgts
+        self.nu = np.empty((0, 2))
 
     def reset(self):
         obs, _ = self.vec.reset()
         self.a = [0.0] * self.n_sgts
+        self.stp_plot = 0
+        self.nu = np.empty((0, 2))                # (stp, Nusselt) per step since reset (rayleigh.py:124)
         return self._np(obs)[0], None
 
     def step(self, a=None):
@@ -90,7 +99,9 @@ class rayleigh(_Single):
                 a[i] = an[i]            # the reference normalises the caller's list in place (:165-168)
         self.a = an.tolist()
         done, trunc = self._episode()
-        return self._np(self.vec.obs)[0], float(self.vec.rwd[0].item()), done, trunc, None
+        rwd = float(self.vec.rwd[0].item())
+        self.nu = np.append(self.nu, np.array([[self.stp - 1, -rwd]]), axis=0)   # get_rwd records (stp, nu) (:273)
+        return self._np(self.vec.obs)[0], rwd, done, trunc, None
 
     def _field(self, k):
         return _fields_2d(self.vec.get_state())[k]
@@ -101,9 +112,12 @@ class rayleigh(_Single):
     T = property(lambda self: self._field(3))
 
     def dump(self, field_name, act_name, nusselt_name=None):
-        """Same text formats as rayleigh.py:344-353 (4 stacked blocks u,v,p,T, '%.5e')."""
+        """Same text formats as rayleigh.py:344-353 (4 stacked blocks u,v,p,T, '%.5e'; the Nusselt history
+        is the negated reward of every step since reset)."""
         np.savetxt(field_name, np.vstack(_fields_2d(self.vec.get_state())), fmt="%.5e")
         np.savetxt(act_name, self.a, fmt="%.5e")
+        if nusselt_name is not None:
+            np.savetxt(nusselt_name, self.nu, fmt="%.5e")
 
     def load(self, filename):
         """Read an init file in the reference's format (rayleigh.py:356-362) and make it the state
@@ -121,6 +135,7 @@ class rayleigh(_Single):
 
 
 class mixing(_Single):
+    _render = "mixing"
     """mixing/mixing.py:16-378"""
 
     def __init__(self, cpu=0, L=1.0, H=1.0, re=100.0, pe=10000.0, side=0.5, C0=1.0, device="cuda:0",
@@ -135,6 +150,7 @@ class mixing(_Single):
     def reset(self):
         obs, _ = self.vec.reset()
         self.a = 1
+        self.stp_plot = 0
         return self._np(obs)[0], None
 
     def step(self, a=None):
@@ -163,6 +179,7 @@ class mixing(_Single):
 
 
 class burgers(_Single):
+    _render = "burgers"
     """burgers/burgers.py:17-227"""
 
     def __init__(self, cpu=0, u_target=0.5, amp=10.0, sigma=0.1, ctrl_pos=1.0, L=2.0, nx=500,
@@ -177,6 +194,7 @@ class burgers(_Single):
     def reset(self):
         obs, _ = self.vec.reset()
         self.a = [0.0]
+        self.stp_plot = 0
         return self._np(obs)[0], None
 
     def step(self, a=None):
@@ -191,8 +209,14 @@ class burgers(_Single):
     up = property(lambda self: self._np(self.vec.get_state())[0, 1])
     upp = property(lambda self: self._np(self.vec.get_state())[0, 2])
 
+    def dump(self, filename):
+        """Same text format as burgers.py:216-222 (columns x, u)."""
+        x = np.linspace(0, self.nx, num=self.nx, endpoint=False) * self.dx
+        np.savetxt(filename, np.transpose(np.vstack((x, self.u))), fmt="%.5e")
+
 
 class shkadov(_Single):
+    _render = "shkadov"
     """shkadov/shkadov.py:16-372"""
 
     def __init__(self, cpu=0, init=True, L0=150.0, n_jets=5, jet_pos=150.0, jet_space=10.0, delta=0.1,
@@ -208,6 +232,7 @@ class shkadov(_Single):
                   "observation_space"):
             setattr(self, k, getattr(v, k))
         self.init = init
+        self.render_style = render_style
         self.rand_init = True          # :49
         self.rand_steps = 400          # :50
         self.u = [0.0] * n_jets
@@ -222,6 +247,7 @@ class shkadov(_Single):
         h=q=1, which is what the reference's own init.py starts from (reset_fields, init.py:14)."""
         self.vec.reset()
         self.u = [0.0] * self.n_jets
+        self.stp_plot = 0
         if self.rand_init and self.init:
             n = random.randint(0, self.rand_steps)                 # :120
             for i in range(n):
@@ -258,6 +284,7 @@ class shkadov(_Single):
 
 
 class sloshing(_Single):
+    _render = "sloshing"
     """sloshing/sloshing.py:16-320"""
 
     def __init__(self, cpu=0, init=True, L=2.5, amp=5.0, alpha=0.0005, g=9.81, device="cuda:0", dtype="f64"):
@@ -278,6 +305,7 @@ class sloshing(_Single):
     def reset(self):
         obs, _ = self.vec.reset()
         self.u = [0.0]
+        self.stp_plot = 0
         return self._np(obs)[0], None
 
     def step(self, u=None):

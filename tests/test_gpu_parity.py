@@ -810,3 +810,54 @@ def test_shkadov_separable_mirror():
             k += 1
     assert maxdiff(e.h, g["h"]) <= 1e-12
     e.close()
+
+
+def test_render_writes_the_reference_layout(tmp_path, monkeypatch):
+    """render() of the single-env mirrors (host side, matplotlib): same directories and file names as the
+    reference's render() methods, dumps readable back with load()."""
+    pytest.importorskip("matplotlib")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("MPLBACKEND", "Agg")
+    rng = np.random.default_rng(0)
+
+    env = E.rayleigh(dtype="f32")
+    env.reset()
+    env.vec.set_ndt_act(3)
+    env.reset()
+    for k in range(2):
+        env.step(rng.uniform(-1, 1, 10).tolist())
+        env.render()
+    for f in ("render/temperature/0.png", "render/temperature/1.png", "render/field/field_1.dat", "render/action/a_1.dat",
+              "render/nu.dat"):
+        assert os.path.getsize(tmp_path / f) > 0, f
+    assert np.loadtxt(tmp_path / "render/nu.dat").shape == (2, 2)
+    T = env.T
+    env.load(str(tmp_path / "render/field/field_1.dat"))
+    env.reset()
+    assert maxdiff(env.T, T) < 1e-4            # '%.5e' text round trip
+    env.close()
+
+    os.rename(tmp_path / "render", tmp_path / "render_rayleigh")
+    env = E.mixing(dtype="f32")
+    env.vec.set_ndt_act(2)
+    env.reset()
+    env.step(2)
+    env.render()
+    assert os.path.getsize(tmp_path / "render/concentration/0.png") > 0
+    assert np.loadtxt(tmp_path / "render/field/field_0.dat").shape == (4 * 102, 102)
+    env.close()
+
+    os.rename(tmp_path / "render", tmp_path / "render_mixing")
+    for make, act, files in ((lambda: E.burgers(dtype="f32"), [0.3], ("gif/0.png", "fields/0.dat")),
+                             (lambda: E.sloshing(dtype="f32"), [0.2], ("height/0.png", "field/field_0.dat", "action/jet_0.dat")),
+                             (lambda: E.shkadov(dtype="f32"), [0.1] * 5, ("height/0.png", "field/field_0.dat", "action/jet_0.dat"))):
+        env = make()
+        if hasattr(env, "rand_init"):
+            env.rand_init = False
+        env.reset()
+        env.step(act)
+        env.render()
+        for f in files:
+            assert os.path.getsize(tmp_path / "render" / f) > 0, f
+        env.close()
+        os.rename(tmp_path / "render", tmp_path / ("render_%d" % len(os.listdir(tmp_path))))
