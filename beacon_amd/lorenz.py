@@ -35,6 +35,7 @@ class lorenz(object):
         self.ht = [self.t]
         self.u = 1
         self.stp = 0
+        self.stp_plot = 0
 
     def reset(self):
         self.reset_fields()
@@ -73,6 +74,16 @@ class lorenz(object):
         done = trunc = (self.stp == self.n_act - 1)
         self.stp += 1
         return obs, rwd, done, trunc, None
+
+    def render(self, mode="human", show=False, dump=True):
+        """Host-side frames in the reference's png/ layout (beacon_amd/render.py; lorenz.py:175-248)."""
+        from . import render as R
+        R.lorenz(self, show, dump)
+
+    def dump(self, filename):
+        """lorenz.py:251-259: columns t, x, y, z of the trajectory since reset, '%.5e'."""
+        hx = np.asarray(self.hx)
+        np.savetxt(filename, np.column_stack((np.asarray(self.ht), hx[:, 0], hx[:, 1], hx[:, 2])), fmt="%.5e")
 
     def close(self):
         pass

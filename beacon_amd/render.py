@@ -160,3 +160,58 @@ def sloshing(env, show=False, dump=True):
     if dump:
         env.dump(os.path.join(fdir, "field_%d.dat" % env.stp_plot), os.path.join(adir, "jet_%d.dat" % env.stp_plot))
     env.stp_plot += 1
+
+
+def _control_strip(fig, pos, value, xlim=(-1.0, 1.0)):
+    ax = fig.add_subplot(*pos)
+    _bare(ax, list(xlim), [0.0, 0.2])
+    _bar(ax, 0.0, 0.05, 0.98 * value, 0.1, value)
+
+
+def lorenz(env, show=False, dump=True):
+    """lorenz.py:175-248: png/gif/<n>.png (trajectory so far + control), png/history.png at the end of the
+    episode, png/lorenz.dat (columns t, x, y, z)."""
+    plt = _plt()
+    env.path = "png"
+    if env.stp_plot == 0:
+        os.makedirs(os.path.join(env.path, "gif"), exist_ok=True)
+    hx, ht = np.asarray(env.hx), np.asarray(env.ht)
+    if env.stp == env.n_act:
+        fig, ax = plt.subplots(figsize=(8, 2))
+        ax.plot(ht, hx[:, 0])
+        ax.set_xlim([0.0, env.t_max]); ax.set_ylim([-20.0, 20.0]); ax.grid()
+        fig.savefig(os.path.join(env.path, "history.png"), dpi=100)
+        plt.close(fig)
+    fig = plt.figure()
+    ax = fig.add_subplot(15, 1, (1, 14), projection="3d")
+    ax.set_axis_off()
+    ax.set_xlim([-20.0, 20.0]); ax.set_ylim([-20.0, 20.0]); ax.set_zlim([0.0, 40.0])
+    ax.plot(hx[:, 0], hx[:, 1], hx[:, 2], linewidth=1)
+    _control_strip(fig, (15, 1, 15), float(env.actions[env.u]))
+    _finish(plt, fig, os.path.join(env.path, "gif", "%d.png" % env.stp_plot), show)
+    if dump:
+        env.dump(os.path.join(env.path, "lorenz.dat"))
+    env.stp_plot += 1
+
+
+def vortex(env, show=False, dump=True):
+    """vortex.py:211-264: png/gif/<n>.png (phase portrait of (ar, ai) + the two controls), png/vortex.dat at
+    the last step of the episode (columns t, ar, ai, yr, yi, kmod, kphase)."""
+    plt = _plt()
+    env.path = "png"
+    if env.stp_plot == 0:
+        os.makedirs(os.path.join(env.path, "gif"), exist_ok=True)
+    hx = np.asarray(env.hx)
+    fig = plt.figure()
+    ax = fig.add_subplot(30, 1, (1, 26))
+    _bare(ax, [-0.04, 0.04], [-0.04, 0.04])
+    ax.plot(hx[:, 0], hx[:, 1], linewidth=1)
+    _control_strip(fig, (30, 1, (27, 28)), float(env.u[0]))
+    _control_strip(fig, (30, 1, (29, 30)), float(env.u[1]))
+    fig.savefig(os.path.join(env.path, "gif", "%d.png" % env.stp_plot), dpi=100)
+    if show:
+        plt.pause(0.0001)
+    plt.close(fig)
+    if dump and env.stp_plot == env.n_act - 1:
+        env.dump(os.path.join(env.path, "vortex.dat"))
+    env.stp_plot += 1

@@ -47,7 +47,9 @@ class vortex(object):
         self.u = np.zeros(2)
         self.kmod = self.kphase = 0.0
         self.hx, self.ht = [self.x.copy()], [self.t]
+        self.ha = [np.zeros(2)]                  # (kmod, kphase) per timestep, first row = u at reset (vortex.py:109-117)
         self.stp = 0
+        self.stp_plot = 0
 
     def reset(self):
         self.reset_fields()
@@ -83,6 +85,7 @@ class vortex(object):
             self.t += self.dt
             self.hx.append(x.copy())
             self.ht.append(self.t)
+            self.ha.append(np.array([self.kmod, self.kphase]))   # vortex.py:183
 
     def get_rwd(self):
         self.yp = self.y
@@ -100,6 +103,15 @@ class vortex(object):
         done = trunc = (self.stp == self.n_act - 1)
         self.stp += 1
         return obs, rwd, done, trunc, None
+
+    def render(self, mode="human", show=False, dump=True):
+        """Host-side frames in the reference's png/ layout (beacon_amd/render.py; vortex.py:211-264)."""
+        from . import render as R
+        R.vortex(self, show, dump)
+
+    def dump(self, filename):
+        """vortex.py:267-279: columns t, ar, ai, yr, yi, kmod, kphase, '%.5e'."""
+        np.savetxt(filename, np.column_stack((np.asarray(self.ht), np.asarray(self.hx), np.asarray(self.ha))), fmt="%.5e")
 
     def close(self):
         pass

@@ -174,3 +174,29 @@ def test_vortex_host_env_matches_reference_episodes():
             assert [d, t] == g[tag + "_done"][k].tolist()
         assert np.array_equal(np.array(e.hx), g[tag + "_hx"])
     assert e.action_space.shape == (2,) and e.observation_space.shape == (8,)
+
+
+def test_lorenz_vortex_render_and_dump(tmp_path, monkeypatch):
+    """Host-only envs: render() writes the reference's png/ layout, dump() its text columns."""
+    pytest.importorskip("matplotlib")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("MPLBACKEND", "Agg")
+    from beacon_amd.lorenz import lorenz
+    from beacon_amd.vortex import vortex
+    env = lorenz()
+    env.reset()
+    for k in range(3):
+        env.step(np.int64(k % 3))
+        env.render()
+    assert os.path.getsize(tmp_path / "png/gif/2.png") > 0
+    d = np.loadtxt(tmp_path / "png/lorenz.dat")
+    assert d.shape == (4, 4) and abs(d[-1, 0] - 3 * env.dt_act) < 1e-12 and np.allclose(d[-1, 1:], env.x, rtol=1e-5)
+    os.rename(tmp_path / "png", tmp_path / "png_lorenz")
+    env = vortex()
+    env.reset()
+    env.step([0.2, -0.4])
+    env.render()
+    assert os.path.getsize(tmp_path / "png/gif/0.png") > 0
+    env.dump(str(tmp_path / "vortex.dat"))
+    d = np.loadtxt(tmp_path / "vortex.dat")
+    assert d.shape == (1 + env.ndt_act, 7) and np.allclose(d[-1, 5:], [env.kmod, env.kphase], rtol=1e-5)
