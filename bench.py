@@ -180,7 +180,9 @@ def main():
                          "kernel": env.kernel_name, "avg_launch_ms": sum(kern_ms) / len(kern_ms),
                          "algorithmic_bytes_per_launch": sum(alg) / len(alg),
                          "note": "effective GB/s = SURVEY 8d algorithmic bytes / launch time; state stays "
-                                 "on-chip/L2 inside the launch, so this is not HBM traffic"},
+                                 "on-chip/L2 inside the launch, so this is not HBM traffic (see `traffic`); on chip "
+                                 "the kernel is VALU-issue bound: SQ_ACTIVE_INST_VALU = 40 % of wave cycles with "
+                                 "2 waves per SIMD (profiles/r01d_sq_counters.json)"},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(init, acts_np[W:], dict(L=L, H=H))
