@@ -270,39 +270,47 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     {
       const real pWh = (w > 0) ? ex(xb, w - 1, 1)[lane] : real(0);
       xb ^= 1;
-      real ur[R + 2], uS[R + 1], uN[R], vr[R + 2], vN[R + 1], vS[R], Tc[R];
+      // float64 (GF): in chunks of CH columns, so that the seven neighbour arrays fit the register file
+      constexpr int CH = GF ? 4 : R;
+      static_assert(R % CH == 0, "chunked predictor");
 #pragma unroll
-      for (int k = 0; k < R + 2; k++) { ur[k] = Ul[(i0 - 1 + k) * SY + j]; vr[k] = Vl[(i0 - 1 + k) * SY + j]; }
+      for (int c0 = 0; c0 < R; c0 += CH) {
+        if (GF) __builtin_amdgcn_sched_barrier(0);   // finish one chunk before loading the next
+        real ur[CH + 2], uS[CH + 1], uN[CH], vr[CH + 2], vN[CH + 1], vS[CH], Tc[CH];
+        const int ic = i0 + c0;
 #pragma unroll
-      for (int k = 0; k < R + 1; k++) { uS[k] = Ul[(i0 + k) * SY + j - 1]; vN[k] = Vl[(i0 - 1 + k) * SY + j + 1]; }
+        for (int k = 0; k < CH + 2; k++) { ur[k] = Ul[(ic - 1 + k) * SY + j]; vr[k] = Vl[(ic - 1 + k) * SY + j]; }
 #pragma unroll
-      for (int k = 0; k < R; k++) { uN[k] = Ul[(i0 + k) * SY + j + 1]; vS[k] = Vl[(i0 + k) * SY + j - 1]; Tc[k] = Tl[(i0 + k) * SY + j]; }
+        for (int k = 0; k < CH + 1; k++) { uS[k] = Ul[(ic + k) * SY + j - 1]; vN[k] = Vl[(ic - 1 + k) * SY + j + 1]; }
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        const int i = i0 + k;
-        const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
-        const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
-        const real pc = p[k];
-        const real pW = (k > 0) ? p[k > 0 ? k - 1 : 0] : pWh;
-        const real pS = from_below(pc, pc);
-        {
-          real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
-          real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
-          real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
-          real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
-          real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
-          real pres = (pc - pW) * rdx;
-          us[k] = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
-        }
-        {
-          real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
-          real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
-          real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
-          real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
-          real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
-          real pres = (pc - pS) * rdy;
-          const real buoy = (KIND == 0) ? Tc[k] : real(0);
-          vs[k] = (j >= 2 && active) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+        for (int k = 0; k < CH; k++) { uN[k] = Ul[(ic + k) * SY + j + 1]; vS[k] = Vl[(ic + k) * SY + j - 1]; Tc[k] = Tl[(ic + k) * SY + j]; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int i = ic + k, kk = c0 + k;
+          const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
+          const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
+          const real pc = p[kk];
+          const real pW = (kk > 0) ? p[kk > 0 ? kk - 1 : 0] : pWh;
+          const real pS = from_below(pc, pc);
+          {
+            real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+            real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
+            real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
+            real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
+            real pres = (pc - pW) * rdx;
+            us[kk] = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
+          }
+          {
+            real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+            real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
+            real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
+            real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
+            real pres = (pc - pS) * rdy;
+            const real buoy = (KIND == 0) ? Tc[k] : real(0);
+            vs[kk] = (j >= 2 && active) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+          }
         }
       }
     }
