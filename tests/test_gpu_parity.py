@@ -306,6 +306,32 @@ def test_ns2d_generic_other_grids_vs_oracle_f64():
     env.close()
 
 
+def test_rayleigh_bench_workload_f32_vs_f64():
+    """The float32 tolerance at the metric configuration: 128x64 developed flow, random actions, two full
+    action steps (2 x 200 timesteps, ~94 Jacobi sweeps each) on the float32 and the float64 register-resident
+    kernels.  Measured drift (scripts/f32_vs_f64.py): observations 1-4e-6, fields <= 4e-6, rewards <= 7e-6,
+    sweep counts differ by at most 2 in <= 10 % of the timesteps; asserted with a 10x margin."""
+    init = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"]
+    B = 32
+    acts = np.random.default_rng(1234).uniform(-1, 1, (2, B, 10))
+    envs = {dt: V.VecRayleigh(B, DEV, dt, init, L=2.56, H=1.28) for dt in ("f32", "f64")}
+    for e in envs.values():
+        _variant(e, 1)
+        e.reset()
+    for k in range(2):
+        out = {}
+        for dt, e in envs.items():
+            obs, rwd, _, _, _ = e.step(acts[k])
+            e.check_status()
+            out[dt] = (obs.double().cpu(), rwd.double().cpu(), e.get_state().double().cpu(), e.sweeps.cpu().numpy())
+        assert float((out["f32"][0] - out["f64"][0]).abs().max()) < 5e-5
+        assert float((out["f32"][1] - out["f64"][1]).abs().max()) < 1e-4
+        assert float((out["f32"][2] - out["f64"][2]).abs().max()) < 5e-5
+        assert int(np.abs(out["f32"][3] - out["f64"][3]).max()) <= 4
+    for e in envs.values():
+        e.close()
+
+
 def test_rayleigh_episode_end_and_overflow():
     g = golden("rayleigh_default")
     env = V.VecRayleigh(2, DEV, "f64", _ray_init(g))
