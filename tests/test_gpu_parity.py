@@ -491,6 +491,33 @@ def test_mixing_fast2_ticket_scheduler_matches_single_launch():
     assert np.max(np.abs(st[0][:, 2] - st[1][:, 2])) < 1e-5
 
 
+def test_mixing_full_steps_f32_vs_f64():
+    """The float32 tolerance of mixing over full action steps (2 x 250 timesteps from rest, random actions):
+    ns2d_fast2 (float32) against the float64 generic kernel.  Measured (scripts/mix_drift.py): observations
+    3e-5 / 8e-5 after one / two steps, u, v, C <= 3e-4, p <= 8e-4, rewards 1e-6; the sweep count differs
+    (by <= 9) in ~40 % of the timesteps because tol = 1e-4 is reached after a handful of sweeps.  Asserted
+    with a margin of ~5x."""
+    B = 8
+    acts = np.random.default_rng(5).integers(0, 4, (2, B))
+    envs = {dt: V.VecMixing(B, DEV, dt) for dt in ("f32", "f64")}
+    for e in envs.values():
+        e.reset()
+    for k in range(2):
+        out = {}
+        for dt, e in envs.items():
+            obs, rwd, _, _, _ = e.step(acts[k])
+            e.check_status()
+            out[dt] = (obs.double().cpu(), rwd.double().cpu(), e.get_state().double().cpu(), e.sweeps.cpu().numpy())
+        assert float((out["f32"][0] - out["f64"][0]).abs().max()) < 4e-4
+        assert float((out["f32"][1] - out["f64"][1]).abs().max()) < 1e-5
+        for i, F in enumerate("uvpC"):
+            assert float((out["f32"][2][:, i] - out["f64"][2][:, i]).abs().max()) < (4e-3 if F == "p" else 1.5e-3), (k, F)
+        assert int(np.abs(out["f32"][3] - out["f64"][3]).max()) <= 30
+    assert envs["f32"].kernel_name.startswith("ns2d_fast2") and envs["f64"].kernel_name == "ns2d_generic_step"
+    for e in envs.values():
+        e.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # burgers
 # ---------------------------------------------------------------------------------------------
