@@ -270,12 +270,13 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     {
       const real pWh = (w > 0) ? ex(xb, w - 1, 1)[lane] : real(0);
       xb ^= 1;
-      // float64 (GF): in chunks of CH columns, so that the seven neighbour arrays fit the register file
-      constexpr int CH = GF ? 4 : R;
+      // float64 (GF) and wide strips: in chunks of CH columns, so that the seven neighbour arrays fit the register file
+      constexpr bool WIDE = (R > 16) || (R > 12 && NW > 8);   // more live values than the wave's register budget
+      constexpr int CH = GF ? 4 : (!WIDE ? R : (R % 5 == 0 ? 5 : (R % 4 == 0 ? 4 : R)));
       static_assert(R % CH == 0, "chunked predictor");
 #pragma unroll
       for (int c0 = 0; c0 < R; c0 += CH) {
-        if (GF) __builtin_amdgcn_sched_barrier(0);   // finish one chunk before loading the next
+        if (CH != R) __builtin_amdgcn_sched_barrier(0);   // finish one chunk before loading the next
         real ur[CH + 2], uS[CH + 1], uN[CH], vr[CH + 2], vN[CH + 1], vS[CH], Tc[CH];
         const int ic = i0 + c0;
 #pragma unroll
@@ -703,6 +704,10 @@ int fast_config(const NS2DArgs<real>& a) {
   if (a.nx == 128 && a.ny == 64 && sizeof(real) == 4) return 1;
   if (a.nx == 50 && a.ny == 50) return 2;
   if (a.nx == 128 && a.ny == 64 && sizeof(real) == 8) return 3;   // fields in global scratch
+  // the reference's other natural aspect ratios (nx = 50 L, ny = 50 H with H = 1), float32
+  if (a.nx == 100 && a.ny == 50 && sizeof(real) == 4) return 4;
+  if (a.nx == 150 && a.ny == 50 && sizeof(real) == 4) return 5;
+  if (a.nx == 200 && a.ny == 50 && sizeof(real) == 4) return 6;
   return 0;
 }
 
@@ -721,6 +726,15 @@ int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     case 2: return launch_fast<real, 50, 50, 5, 0>(a, batch, s);
     case 3:
       if constexpr (std::is_same<real, double>::value) return launch_fast<double, 128, 64, BCN_R128D, 0, BCN_GFD>(a, batch, s);
+      break;
+    case 4:
+      if constexpr (std::is_same<real, float>::value) return launch_fast<float, 100, 50, 10, 0>(a, batch, s);
+      break;
+    case 5:
+      if constexpr (std::is_same<real, float>::value) return launch_fast<float, 150, 50, 15, 0>(a, batch, s);
+      break;
+    case 6:
+      if constexpr (std::is_same<real, float>::value) return launch_fast<float, 200, 50, 25, 0>(a, batch, s);
       break;
     default: break;
   }

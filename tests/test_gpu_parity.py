@@ -332,6 +332,44 @@ def test_rayleigh_bench_workload_f32_vs_f64():
         e.close()
 
 
+@pytest.mark.parametrize("L,nx", [(2.0, 100), (3.0, 150), (4.0, 200)])
+def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
+    """Register-resident instantiations for the reference's other natural aspect ratios (nx = 50 L, ny = 50):
+    float32, smooth synthetic start, 2 x 10 timesteps, against the float64 oracle (5e-5; p 50x looser) and with
+    identical replicas bit-identical; the sweep counts within max(4, 4 %) as for the 100x100 test."""
+    ny = 50
+    rng = np.random.default_rng(17)
+    x, y = (np.arange(nx + 2) - 0.5) / nx, (np.arange(ny + 2) - 0.5) / ny
+    init = np.zeros((4, nx + 2, ny + 2))
+    init[3] = (0.5 - y)[None, :] + 0.1 * np.sin(2 * np.pi * L * x)[:, None] * np.sin(np.pi * y)[None, :] \
+        + 1e-3 * rng.standard_normal((nx + 2, ny + 2))
+    B, NDT = 4, 10
+    acts = rng.uniform(-1, 1, (2, B, 10))
+    acts[:, 3] = acts[:, 0]
+    env = V.VecRayleigh(B, DEV, "f32", init, L=L, H=1.0)
+    env.set_ndt_act(NDT)
+    _variant(env, 1)
+    env.reset()
+    oracles = [O.rayleigh(init_fields=init, L=L, H=1.0) for _ in range(3)]
+    for o in oracles:
+        o.cfg.ndt_act = NDT
+        o.reset()
+    for k in range(2):
+        obs, rwd, _, _, _ = env.step(acts[k])
+        env.check_status()
+        assert env.kernel_name == "ns2d_fast_step"
+        raw = env.get_state()
+        st, sw = dev2ref(raw), env.sweeps.cpu().numpy()
+        assert bool((raw[3] == raw[0]).all()) and np.array_equal(sw[3], sw[0])
+        for b, o in enumerate(oracles):
+            ob, rw, _, _, _ = o.step(acts[k, b].tolist())
+            for i, F in enumerate("uvpT"):
+                assert maxdiff(st[b][i], o.st[i]) <= 5e-5 * (50 if F == "p" else 1), (k, b, F)
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5 and abs(float(rwd[b]) - rw) <= 2e-4
+            assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(4, 0.04 * o.itp)), (sw[b], o.itp)
+    env.close()
+
+
 def test_rayleigh_episode_end_and_overflow():
     g = golden("rayleigh_default")
     env = V.VecRayleigh(2, DEV, "f64", _ray_init(g))
