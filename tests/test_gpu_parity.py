@@ -952,3 +952,17 @@ def test_render_writes_the_reference_layout(tmp_path, monkeypatch):
             assert os.path.getsize(tmp_path / "render" / f) > 0, f
         env.close()
         os.rename(tmp_path / "render", tmp_path / ("render_%d" % len(os.listdir(tmp_path))))
+
+
+def test_c_abi_error_behaviour():
+    """Errors cross the C ABI as return codes + bcn_last_error() text and surface as BeaconHipError (the
+    reference prints and exits): out-of-range configurations at create time and NULL handles
+    (the Poisson overflow status word is covered by test_rayleigh_episode_end_and_overflow)."""
+    from beacon_amd import _lib
+    with pytest.raises(_lib.BeaconHipError, match="burgers cfg out of range"):
+        V.VecBurgers(2, DEV, "f32", nx=10000)          # > 8192 cells
+    with pytest.raises(_lib.BeaconHipError):
+        V.VecRayleigh(0, DEV, "f32", None)             # batch must be positive
+    lib = _lib.load()
+    assert lib.bcn_batch(None) == 0 and lib.bcn_destroy(None) == 0            # NULL handle: inert, like free(NULL)
+    assert lib.bcn_get_state(None, None, 0, None) == 1 and b"null" in lib.bcn_last_error()   # BCN_ERR_ARG
