@@ -966,3 +966,35 @@ def test_c_abi_error_behaviour():
     lib = _lib.load()
     assert lib.bcn_batch(None) == 0 and lib.bcn_destroy(None) == 0            # NULL handle: inert, like free(NULL)
     assert lib.bcn_get_state(None, None, 0, None) == 1 and b"null" in lib.bcn_last_error()   # BCN_ERR_ARG
+
+
+def test_plain_c_consumer_of_the_c_abi(tmp_path):
+    """include/beacon_hip.h + libbeacon_hip.so from a plain C program (gcc, HIP runtime API for the device
+    buffers; no Python, no torch in the process): burgers, 4 replicas, float64, 3 steps, against the oracle."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("gcc / ROCm headers not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "burgers_smoke")
+    libdir = os.path.join(root, "beacon_amd")
+    cmd = ["gcc", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "tests", "c_abi", "burgers_smoke.c"), "-o", exe, "-L" + libdir, "-lbeacon_hip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "kernel ok" in r.stdout, (r.stdout[-500:], r.stderr[-1000:])
+    got_obs, got_rwd = {}, {}
+    for line in r.stdout.splitlines():
+        t = line.split()
+        if t[0] == "obs":
+            got_obs[(int(t[1]), int(t[2]))] = np.array([float(x) for x in t[3:]])
+        elif t[0] == "rwd":
+            got_rwd[(int(t[1]), int(t[2]))] = float(t[3])
+    for b in range(4):
+        o = O.burgers()
+        o.reset()
+        for s_ in range(3):
+            ob, rw, _, _, _ = o.step([0.25 * (b - 1.5) * (s_ + 1)], 0.02 * (b + 1) - 0.01 * s_)
+            assert maxdiff(got_obs[(s_, b)], ob) <= 1e-12 and abs(got_rwd[(s_, b)] - rw) <= 1e-12
