@@ -30,6 +30,9 @@
 #ifndef BCN_R128
 #define BCN_R128 16
 #endif
+#ifndef BCN_R50
+#define BCN_R50 5     // columns per lane of the 50x50 kernels
+#endif
 #ifndef BCN_GFD
 #define BCN_GFD 2   // float64 128x64: 1 = u, v, T in global scratch, 2 = u, v in LDS and T in global scratch
 #endif
@@ -723,7 +726,7 @@ int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     case 1:
       if constexpr (std::is_same<real, float>::value) return launch_fast<float, 128, 64, BCN_R128, 0>(a, batch, s);
       break;
-    case 2: return launch_fast<real, 50, 50, 5, 0>(a, batch, s);
+    case 2: return launch_fast<real, 50, 50, BCN_R50, 0>(a, batch, s);
     case 3:
       if constexpr (std::is_same<real, double>::value) return launch_fast<double, 128, 64, BCN_R128D, 0, BCN_GFD>(a, batch, s);
       break;
