@@ -642,10 +642,9 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   if (GF && (!a.fscr || a.fscr_stride < G::scratch_elems())) { bcn_set_error("fast path: field scratch missing"); return BCN_ERR_UNSUPPORTED; }
   const size_t lds = G::lds_elems() * sizeof(real);
   auto k = ns2d_fast_step<real, NX, NY, R, KIND, EQ, GF>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (ns2d_first_on_device(attr_set)) {
     BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
@@ -653,10 +652,9 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
     auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ, GF>;
-    static bool attr_set2 = false;
-    if (!attr_set2) {
+    static unsigned long long attr_set2 = 0;
+    if (ns2d_first_on_device(attr_set2)) {
       BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set2 = true;
     }
     const int nchunk = a.ndt_act / SQ;
     c.sched_q = SQ; c.order = nullptr; c.first_chunk = 1; c.last_chunk = 1; c.it_begin = 0; c.it_end = a.ndt_act;

@@ -536,8 +536,8 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   const SchedParams& sp = ns2d_sched_params();
   if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * sp.q && a.sched_ctl) {
     auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ>;
-    static bool set2 = false;
-    if (!set2) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set2 = true; }
+    static unsigned long long set2 = 0;
+    if (ns2d_first_on_device(set2)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nchunk = a.ndt_act / sp.q;
     c.sched_q = sp.q;
     BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, sizeof(SchedCtl) + (size_t)batch * sizeof(unsigned int), s));
@@ -547,8 +547,8 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     return BCN_OK;
   }
   auto k = ns2d_fast2_step<real, NX, NY, R, KIND, EQ>;
-  static bool set = false;
-  if (!set) { BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+  static unsigned long long set = 0;
+  if (ns2d_first_on_device(set)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   BCN_HIP(hipGetLastError());
   if (a.launched) *a.launched = "ns2d_fast2_step";

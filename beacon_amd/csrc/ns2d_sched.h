@@ -79,6 +79,17 @@ __device__ __forceinline__ void ns2d_sched_loop(const NS2DArgs<real>& A, SchedCt
   }
 }
 
+// "first launch of this kernel on the current device": the dynamic-LDS attribute is per device, and a process may
+// hold handles on several devices (one process per GPU is the deployment, not a requirement of the ABI)
+inline bool ns2d_first_on_device(unsigned long long& seen) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (seen & bit) return false;
+  seen |= bit;
+  return true;
+}
+
 // host side: BCN_SCHED = 0 plain launch, 1 two-launch LPT split (ns2d_fast only), 2 ticketed chunks
 // (default); BCN_SCHED_GRID persistent workgroups (default: one per CU); BCN_SCHED_Q timesteps per chunk
 struct SchedParams {
