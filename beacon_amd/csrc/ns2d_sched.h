@@ -94,14 +94,15 @@ inline bool ns2d_first_on_device(unsigned long long& seen) {
 // (default); BCN_SCHED_GRID persistent workgroups (default: one per CU); BCN_SCHED_Q timesteps per chunk
 struct SchedParams {
   int mode, grid, q;
+  bool q_set;   // BCN_SCHED_Q given: overrides the per-kernel default
 };
 inline const SchedParams& ns2d_sched_params() {
-  static SchedParams p = {-1, 0, 10};
+  static SchedParams p = {-1, 0, 10, false};
   if (p.mode < 0) {
     const char* e = getenv("BCN_SCHED");
     const char* g = getenv("BCN_SCHED_GRID");
     const char* q = getenv("BCN_SCHED_Q");
-    if (q && atoi(q) > 0) p.q = atoi(q);
+    if (q && atoi(q) > 0) { p.q = atoi(q); p.q_set = true; }
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
