@@ -1,0 +1,157 @@
+// ubench_sweep.hip -- Jacobi sweep mappings for a 128x64 float32 grid on one CU (8 waves), isolated from the
+// rest of the kernel: A = lanes along y, 16 columns per lane (ns2d_fast.hip today: 2 DPP adds per cell);
+// B = lanes along x with 2 columns per lane, 8 rows per wave (1 DPP add per cell, y-neighbours in registers,
+// two halo rows per wave through LDS).  Same arithmetic per cell, same reduction, one barrier per sweep.
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=on scripts/ubench_sweep.hip -o scripts/ubench_sweep
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+
+__device__ __forceinline__ float add2dpp(float acc, float c) {   // acc + c(lane+1) + c(lane-1), 0 outside
+  float t, r;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %2, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(t), "=v"(r) : "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ float add_shl(float acc, float c) {   // acc + c(lane+1)
+  float r;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ float add_shr(float acc, float c) {   // acc + c(lane-1)
+  float r;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(c), "v"(acc));
+  return r;
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ float dppf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, CTRL < 0x140));
+}
+__device__ __forceinline__ float wave_sum63(float s) {
+  s += dppf<0x111, 0xf>(s); s += dppf<0x112, 0xf>(s); s += dppf<0x114, 0xf>(s); s += dppf<0x118, 0xf>(s);
+  s += dppf<0x142, 0xa>(s); s += dppf<0x143, 0xc>(s);
+  return s;
+}
+
+// cell variants of mapping A: 0 = fused DPP pair behind one s_nop (the kernel), 1 = compiler-scheduled DPP builtins,
+// 2 = both neighbours by v_mov_dpp, then plain adds, 3 = (n + e) + (s + w) with two independent fused DPP adds
+template <int VAR>
+__device__ __forceinline__ float nsum(float e, float w, float c) {
+  if (VAR == 0) return add2dpp(e + w, c);
+  if (VAR == 1) return (e + w) + dppf<0x130, 0xf>(c) + dppf<0x138, 0xf>(c);
+  if (VAR == 2) { const float n = dppf<0x130, 0xf>(c), s = dppf<0x138, 0xf>(c); return (e + w) + (n + s); }
+  return add_shl(e, c) + add_shr(w, c);
+}
+
+// ---- A: lanes along y ------------------------------------------------------------------------
+template <int VAR>
+__global__ __launch_bounds__(512) void sweepA(float* out, const float* in, int nsweep, float cx) {
+  constexpr int R = 16, NW = 8;
+  __shared__ float ex[2][NW][2][64];
+  __shared__ __attribute__((aligned(16))) float errp[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float A[R], B[R], nb[R];
+  for (int k = 0; k < R; k++) { A[k] = 0; nb[k] = in[(blockIdx.x * 512 + tid) * R + k]; }
+  const float cB = (lane == 0 || lane == 63) ? cx : 0.f, wl = 1.f + (lane == 0) + (lane == 63);
+  const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
+  float hW = 0, hE = 0, hWr = 0, hEr = 0, e8[8], errsum = 0;
+  for (int q = 0; q < 8; q++) e8[q] = 0;
+  int xb = 0;
+#define CELLA(c, e, wv, nbk) (cx * nsum<VAR>(e, wv, c) + (cB * (c) + (nbk)))
+#define SWEEPA(S, D)                                                                     \
+  {                                                                                      \
+    float acc = 0;                                                                       \
+    _Pragma("unroll") for (int k = 1; k < R - 1; k++) { float ph = CELLA(S[k], S[k + 1], S[k - 1], nb[k]); float d = ph - S[k]; acc += d * d; D[k] = ph; } \
+    const float pI = wl * acc;                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    { float s = ((e8[0] + e8[1]) + (e8[2] + e8[3])) + ((e8[4] + e8[5]) + (e8[6] + e8[7])); errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0)); } \
+    hW = (w > 0) ? hWr : S[0]; hE = (w < NW - 1) ? hEr : S[R - 1];                       \
+    float p0 = CELLA(S[0], S[1], hW, nb[0]), pl = CELLA(S[R - 1], hE, S[R - 2], nb[R - 1]); \
+    float d0 = p0 - S[0], dl = pl - S[R - 1]; D[0] = p0; D[R - 1] = pl;                  \
+    float tot = wave_sum63(pI + wl * (d0 * d0) + wl * (dl * dl));                        \
+    ex[xb][w][0][lane] = p0; ex[xb][w][1][lane] = pl; if (lane == 63) errp[xb][w] = tot; \
+    __syncthreads();                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 8; q++) e8[q] = errp[xb][q];                   \
+    hWr = ex[xb][wm][1][lane]; hEr = ex[xb][wp][0][lane]; xb ^= 1;                       \
+  }
+  for (int it = 0; it < nsweep; it += 2) { SWEEPA(A, B) SWEEPA(B, A) }
+  float r = errsum;
+  for (int k = 0; k < R; k++) r += A[k];
+  out[blockIdx.x * 512 + tid] = r;
+}
+
+// ---- B: lanes along x, two columns per lane, 8 rows per wave -----------------------------------
+__global__ __launch_bounds__(512) void sweepB(float* out, const float* in, int nsweep, float cx) {
+  constexpr int NR = 8, NW = 8;   // rows per wave; cell (r, c): row w*8 + r, column 2*lane + c
+  __shared__ float ex[2][NW][2][2][64];   // [buf][wave][bottom row | top row][column 0/1][lane]
+  __shared__ __attribute__((aligned(16))) float errp[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float A[NR][2], B[NR][2], nb[NR][2];
+  for (int r = 0; r < NR; r++) for (int c = 0; c < 2; c++) { A[r][c] = 0; nb[r][c] = in[(blockIdx.x * 512 + tid) * 16 + r * 2 + c]; }
+  // x walls: lane 0 column 0 / lane 63 column 1 mirror themselves (Neumann); y walls: rows 0 / 63 mirror themselves
+  const float cW = (lane == 0) ? cx : 0.f, cE = (lane == 63) ? cx : 0.f;
+  const float w0 = 1.f + (lane == 0), w1 = 1.f + (lane == 63);
+  const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
+  float hS[2] = {0, 0}, hN[2] = {0, 0}, hSr[2] = {0, 0}, hNr[2] = {0, 0}, e8[8], errsum = 0;
+  for (int q = 0; q < 8; q++) e8[q] = 0;
+  int xb = 0;
+  // cell (r, 0): west = lane-1's column 1 (DPP), east = own column 1; cell (r, 1): west = own column 0, east = lane+1's column 0
+#define CELLB0(S, r, s_, n_) (cx * add_shr(((n_) + (s_)) + S[r][1], S[r][1]) + (cW * S[r][0] + nb[r][0]))
+#define CELLB1(S, r, s_, n_) (cx * add_shl(((n_) + (s_)) + S[r][0], S[r][0]) + (cE * S[r][1] + nb[r][1]))
+#define ROWB(S, D, r, s0, s1, n0, n1, rw)                                                \
+  { float p0 = CELLB0(S, r, s0, n0), p1 = CELLB1(S, r, s1, n1);                          \
+    float d0 = p0 - S[r][0], d1 = p1 - S[r][1]; acc += (rw) * (w0 * (d0 * d0) + w1 * (d1 * d1)); D[r][0] = p0; D[r][1] = p1; }
+#define SWEEPB(S, D)                                                                     \
+  {                                                                                      \
+    float acc = 0;                                                                       \
+    _Pragma("unroll") for (int r = 1; r < NR - 1; r++) ROWB(S, D, r, S[r - 1][0], S[r - 1][1], S[r + 1][0], S[r + 1][1], 1.f) \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    { float s = ((e8[0] + e8[1]) + (e8[2] + e8[3])) + ((e8[4] + e8[5]) + (e8[6] + e8[7])); errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0)); } \
+    _Pragma("unroll") for (int c = 0; c < 2; c++) { hS[c] = (w > 0) ? hSr[c] : S[0][c]; hN[c] = (w < NW - 1) ? hNr[c] : S[NR - 1][c]; } \
+    const float rwb = (w == 0) ? 2.f : 1.f, rwt = (w == NW - 1) ? 2.f : 1.f;             \
+    ROWB(S, D, 0, hS[0], hS[1], S[1][0], S[1][1], rwb)                                   \
+    ROWB(S, D, NR - 1, S[NR - 2][0], S[NR - 2][1], hN[0], hN[1], rwt)                    \
+    float tot = wave_sum63(acc);                                                         \
+    _Pragma("unroll") for (int c = 0; c < 2; c++) { ex[xb][w][0][c][lane] = D[0][c]; ex[xb][w][1][c][lane] = D[NR - 1][c]; } \
+    if (lane == 63) errp[xb][w] = tot;                                                   \
+    __syncthreads();                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 8; q++) e8[q] = errp[xb][q];                   \
+    _Pragma("unroll") for (int c = 0; c < 2; c++) { hSr[c] = ex[xb][wm][1][c][lane]; hNr[c] = ex[xb][wp][0][c][lane]; } \
+    xb ^= 1;                                                                             \
+  }
+  for (int it = 0; it < nsweep; it += 2) { SWEEPB(A, B) SWEEPB(B, A) }
+  float r = errsum;
+  for (int q = 0; q < NR; q++) r += A[q][0] + A[q][1];
+  out[blockIdx.x * 512 + tid] = r;
+}
+
+int main() {
+  const int nwg = 256, nsweep = 4000;
+  float *in, *out;
+  hipMalloc(&in, nwg * 512 * 16 * sizeof(float));
+  hipMalloc(&out, nwg * 512 * sizeof(float));
+  std::vector<float> h(nwg * 512 * 16);
+  for (size_t i = 0; i < h.size(); i++) h[i] = 1e-3f * (float)((i * 2654435761u) % 1000) / 1000.f;
+  hipMemcpy(in, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  int clk = 0;
+  hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
+  const char* names[5] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
+                          "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell"};
+  for (int rep = 0; rep < 2; rep++)
+    for (int v = 0; v < 5; v++) {
+      hipEventRecord(e0);
+      if (v == 0) hipLaunchKernelGGL(sweepA<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 1) hipLaunchKernelGGL(sweepA<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 2) hipLaunchKernelGGL(sweepA<2>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 3) hipLaunchKernelGGL(sweepA<3>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 4) hipLaunchKernelGGL(sweepB, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+      if (rep) printf("%-45s %.0f ns per sweep = ~%.0f cycles at %.2f GHz (max clock)\n", names[v], ms * 1e6 / nsweep, ms * 1e6 / nsweep * (clk * 1e-6), clk * 1e-6);
+    }
+  return 0;
+}
