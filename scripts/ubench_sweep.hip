@@ -127,6 +127,63 @@ __global__ __launch_bounds__(512) void sweepB(float* out, const float* in, int n
   out[blockIdx.x * 512 + tid] = r;
 }
 
+// ---- C: mapping A with TWO sweeps per barrier: depth-2 halos, the strip-edge neighbours' columns are computed
+// redundantly in the first sub-sweep (R+2 cells), the second sub-sweep needs nothing from other waves (R cells);
+// both residuals are reduced and published together.  Same arithmetic per cell and per residual as A0.
+__global__ __launch_bounds__(512) void sweepC(float* out, const float* in, int nsweep, float cx) {
+  constexpr int R = 16, NW = 8;
+  __shared__ float ex[2][NW][4][64];   // columns 0, 1, R-2, R-1 of the newest phi
+  __shared__ __attribute__((aligned(16))) float errp[2][2][8];
+  __shared__ float nbx[NW][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float A[R], B[R], nb[R];
+  for (int k = 0; k < R; k++) { A[k] = 0; nb[k] = in[(blockIdx.x * 512 + tid) * R + k]; }
+  const float cB = (lane == 0 || lane == 63) ? cx : 0.f, wl = 1.f + (lane == 0) + (lane == 63);
+  const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
+  nbx[w][0][lane] = nb[0]; nbx[w][1][lane] = nb[R - 1];
+  __syncthreads();
+  const float nbW = nbx[wm][1][lane], nbE = nbx[wp][0][lane];
+  float hW1 = 0, hW2 = 0, hE1 = 0, hE2 = 0, e1[8], e2[8], errsum = 0;
+  for (int q = 0; q < 8; q++) { e1[q] = 0; e2[q] = 0; }
+  int xb = 0;
+#define CELLC(c, e, wv, nbk) (cx * add2dpp((e) + (wv), c) + (cB * (c) + (nbk)))
+  for (int it = 0; it < nsweep; it += 2) {
+    // sub-sweep 1: A -> B on columns -1 .. R; interior first
+    float acc1 = 0;
+#pragma unroll
+    for (int k = 1; k < R - 1; k++) { float ph = CELLC(A[k], A[k + 1], A[k - 1], nb[k]); float d = ph - A[k]; acc1 += d * d; B[k] = ph; }
+    __builtin_amdgcn_sched_barrier(0);
+    { float s1 = ((e1[0] + e1[1]) + (e1[2] + e1[3])) + ((e1[4] + e1[5]) + (e1[6] + e1[7]));
+      float s2 = ((e2[0] + e2[1]) + (e2[2] + e2[3])) + ((e2[4] + e2[5]) + (e2[6] + e2[7]));
+      errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s1), 0)) +
+                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s2), 0)); }
+    const float a_w1 = (w > 0) ? hW1 : A[0], a_e1 = (w < NW - 1) ? hE1 : A[R - 1];   // phi_{n-1} at columns -1, R
+    float p0 = CELLC(A[0], A[1], a_w1, nb[0]), pl = CELLC(A[R - 1], a_e1, A[R - 2], nb[R - 1]);
+    float pW = CELLC(hW1, A[0], hW2, nbW), pE = CELLC(hE1, hE2, A[R - 1], nbE);   // neighbours' edge columns, redundantly
+    { float d0 = p0 - A[0], dl = pl - A[R - 1]; acc1 += d0 * d0; acc1 += dl * dl; }
+    B[0] = p0; B[R - 1] = pl;
+    pW = (w > 0) ? pW : p0; pE = (w < NW - 1) ? pE : pl;                           // walls: Neumann ghost = new edge value
+    // sub-sweep 2: B -> A on the own columns, nothing needed from other waves
+    float acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const float e = (k < R - 1) ? B[k < R - 1 ? k + 1 : 0] : pE, wv = (k > 0) ? B[k > 0 ? k - 1 : 0] : pW;
+      float ph = CELLC(B[k], e, wv, nb[k]); float d = ph - B[k]; acc2 += d * d; A[k] = ph;
+    }
+    const float t1 = wave_sum63(wl * acc1), t2 = wave_sum63(wl * acc2);
+    ex[xb][w][0][lane] = A[0]; ex[xb][w][1][lane] = A[1]; ex[xb][w][2][lane] = A[R - 2]; ex[xb][w][3][lane] = A[R - 1];
+    if (lane == 63) { errp[xb][0][w] = t1; errp[xb][1][w] = t2; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) { e1[q] = errp[xb][0][q]; e2[q] = errp[xb][1][q]; }
+    hW1 = ex[xb][wm][3][lane]; hW2 = ex[xb][wm][2][lane]; hE1 = ex[xb][wp][0][lane]; hE2 = ex[xb][wp][1][lane];
+    xb ^= 1;
+  }
+  float r = errsum;
+  for (int k = 0; k < R; k++) r += A[k] + B[k];
+  out[blockIdx.x * 512 + tid] = r;
+}
+
 int main() {
   const int nwg = 256, nsweep = 4000;
   float *in, *out;
@@ -139,16 +196,17 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   int clk = 0;
   hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-  const char* names[5] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
-                          "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell"};
+  const char* names[6] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
+                          "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell", "C  A0 with two sweeps per barrier (depth-2 halos)"};
   for (int rep = 0; rep < 2; rep++)
-    for (int v = 0; v < 5; v++) {
+    for (int v = 0; v < 6; v++) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(sweepA<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 1) hipLaunchKernelGGL(sweepA<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 2) hipLaunchKernelGGL(sweepA<2>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 3) hipLaunchKernelGGL(sweepA<3>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 4) hipLaunchKernelGGL(sweepB, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 5) hipLaunchKernelGGL(sweepC, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms = 0; hipEventElapsedTime(&ms, e0, e1);
       if (rep) printf("%-45s %.0f ns per sweep = ~%.0f cycles at %.2f GHz (max clock)\n", names[v], ms * 1e6 / nsweep, ms * 1e6 / nsweep * (clk * 1e-6), clk * 1e-6);
