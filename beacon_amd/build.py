@@ -1,8 +1,13 @@
 """In-tree build of libbeacon_hip.so (hand-written HIP for gfx950) with hipcc.
 
-The shared object is git-ignored but travels to the GPU box with the snapshot; it is
-rebuilt whenever a source under csrc/ or include/ is newer than it."""
+The shared object is git-ignored but travels to the GPU box with the snapshot.  Staleness is decided by
+CONTENT, not by mtime (a snapshot or a fresh checkout may reset file times): the library carries a sidecar
+`libbeacon_hip.so.sig` with a hash of every source, header and flag it was built from.  Concurrent builds
+(N ranks of one node importing the package at once) are serialised by a file lock and build into a
+per-process object directory."""
+import fcntl
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -39,11 +44,22 @@ def _deps():
     return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
 
 
+def signature():
+    """Hash of everything the library is built from: sources, headers, flags."""
+    h = hashlib.sha256()
+    h.update(repr((ARCH, FLAGS, sorted(FILE_FLAGS.items()))).encode())
+    for f in sorted(_deps()):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".sig"):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in _deps())
+    with open(LIB + ".sig") as fh:
+        return fh.read().strip() != signature()
 
 
 def build_lib(force=False, verbose=False):
@@ -54,26 +70,37 @@ def build_lib(force=False, verbose=False):
     if cc is None:
         raise RuntimeError("hipcc not found: cannot build libbeacon_hip.so")
     os.makedirs(OBJ, exist_ok=True)
-    hdr_t = max(os.path.getmtime(f) for f in _deps() if f.endswith(".h"))
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)               # one builder at a time per checkout
+        try:
+            if not force and not stale():              # another process built it while we waited
+                return LIB
+            sig = signature()
+            objdir = os.path.join(OBJ, "p%d" % os.getpid())
+            os.makedirs(objdir, exist_ok=True)
 
-    def one(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-                and os.path.getmtime(obj) > hdr_t):
-            return obj
-        cmd = [cc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INC, "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        return obj
+            def one(src):
+                obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+                cmd = [cc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INC, "-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(one, sources()))
-    cmd = [cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+            with ThreadPoolExecutor(max_workers=4) as ex:
+                objs = list(ex.map(one, sources()))
+            tmp = "%s.tmp%d" % (LIB, os.getpid())
+            cmd = [cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+            with open(LIB + ".sig.tmp", "w") as fh:
+                fh.write(sig + "\n")
+            os.replace(LIB + ".sig.tmp", LIB + ".sig")
+            shutil.rmtree(objdir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
