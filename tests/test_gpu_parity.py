@@ -370,6 +370,39 @@ def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
     env.close()
 
 
+@pytest.mark.parametrize("L,H,n_sgts,ra", [(1.5, 1.0, 2, 2.0e4), (1.0, 1.5, 5, 5.0e4), (2.2, 1.3, 7, 1.0e4)])
+def test_rayleigh_odd_configs_generic_vs_oracle_f64(L, H, n_sgts, ra):
+    """Constructor-space coverage of the generic kernel: grids that are not multiples of anything (75x50, 50x75,
+    110x65), segment counts that do not divide nx (the reference leaves the bottom ghost cells right of the last
+    segment unwritten, rayleigh.py:199-202), other Rayleigh numbers; float64 against the oracle, 2 x 4 timesteps."""
+    nx, ny = int(50 * L), int(50 * H)
+    rng = np.random.default_rng(int(1000 * L + 10 * H + n_sgts))
+    x, y = (np.arange(nx + 2) - 0.5) / nx, (np.arange(ny + 2) - 0.5) / ny
+    init = np.zeros((4, nx + 2, ny + 2))
+    init[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x * L)[:, None] * np.sin(np.pi * y)[None, :]
+    B, NDT = 3, 4
+    acts = rng.uniform(-1, 1, (2, B, n_sgts))
+    env = V.VecRayleigh(B, DEV, "f64", init, L=L, H=H, n_sgts=n_sgts, ra=ra)
+    env.set_ndt_act(NDT)
+    env.reset()
+    oracles = [O.rayleigh(init_fields=init, L=L, H=H, n_sgts=n_sgts, ra=ra) for _ in range(B)]
+    for o in oracles:
+        o.cfg.ndt_act = NDT
+        o.reset()
+    for k in range(2):
+        obs, rwd, _, _, _ = env.step(acts[k])
+        env.check_status()
+        assert env.kernel_name == "ns2d_generic_step"
+        st, sw = dev2ref(env.get_state()), env.sweeps.cpu().numpy()
+        for b, o in enumerate(oracles):
+            ob, rw, _, _, _ = o.step(acts[k, b].tolist())
+            for i, F in enumerate("uvpT"):
+                assert maxdiff(st[b][i], o.st[i]) <= F64_TOL * (50 if F == "p" else 1), (k, b, F)
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and abs(float(rwd[b]) - rw) <= 1e-8
+            assert np.max(np.abs(sw[b] - o.itp)) <= 1
+    env.close()
+
+
 def test_rayleigh_episode_end_and_overflow():
     g = golden("rayleigh_default")
     env = V.VecRayleigh(2, DEV, "f64", _ray_init(g))
