@@ -46,18 +46,17 @@ __device__ __forceinline__ float nsum(float e, float w, float c) {
 }
 
 // ---- A: lanes along y ------------------------------------------------------------------------
-template <int VAR>
-__global__ __launch_bounds__(512) void sweepA(float* out, const float* in, int nsweep, float cx) {
-  constexpr int R = 16, NW = 8;
+template <int VAR, int R = 16, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void sweepA(float* out, const float* in, int nsweep, float cx) {
   __shared__ float ex[2][NW][2][64];
   __shared__ __attribute__((aligned(16))) float errp[2][16];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   float A[R], B[R], nb[R];
-  for (int k = 0; k < R; k++) { A[k] = 0; nb[k] = in[(blockIdx.x * 512 + tid) * R + k]; }
+  for (int k = 0; k < R; k++) { A[k] = 0; nb[k] = in[((blockIdx.x * 1024 + tid) * 16 + k) % (256 * 512 * 16)]; }
   const float cB = (lane == 0 || lane == 63) ? cx : 0.f, wl = 1.f + (lane == 0) + (lane == 63);
   const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
-  float hW = 0, hE = 0, hWr = 0, hEr = 0, e8[8], errsum = 0;
-  for (int q = 0; q < 8; q++) e8[q] = 0;
+  float hW = 0, hE = 0, hWr = 0, hEr = 0, e8[NW], errsum = 0;
+  for (int q = 0; q < NW; q++) e8[q] = 0;
   int xb = 0;
 #define CELLA(c, e, wv, nbk) (cx * nsum<VAR>(e, wv, c) + (cB * (c) + (nbk)))
 #define SWEEPA(S, D)                                                                     \
@@ -66,20 +65,21 @@ __global__ __launch_bounds__(512) void sweepA(float* out, const float* in, int n
     _Pragma("unroll") for (int k = 1; k < R - 1; k++) { float ph = CELLA(S[k], S[k + 1], S[k - 1], nb[k]); float d = ph - S[k]; acc += d * d; D[k] = ph; } \
     const float pI = wl * acc;                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    { float s = ((e8[0] + e8[1]) + (e8[2] + e8[3])) + ((e8[4] + e8[5]) + (e8[6] + e8[7])); errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0)); } \
+    { _Pragma("unroll") for (int st = 1; st < NW; st *= 2) _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) e8[q] += e8[q + st]; \
+      errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e8[0]), 0)); } \
     hW = (w > 0) ? hWr : S[0]; hE = (w < NW - 1) ? hEr : S[R - 1];                       \
     float p0 = CELLA(S[0], S[1], hW, nb[0]), pl = CELLA(S[R - 1], hE, S[R - 2], nb[R - 1]); \
     float d0 = p0 - S[0], dl = pl - S[R - 1]; D[0] = p0; D[R - 1] = pl;                  \
     float tot = wave_sum63(pI + wl * (d0 * d0) + wl * (dl * dl));                        \
     ex[xb][w][0][lane] = p0; ex[xb][w][1][lane] = pl; if (lane == 63) errp[xb][w] = tot; \
     __syncthreads();                                                                     \
-    _Pragma("unroll") for (int q = 0; q < 8; q++) e8[q] = errp[xb][q];                   \
+    _Pragma("unroll") for (int q = 0; q < NW; q++) e8[q] = errp[xb][q];                  \
     hWr = ex[xb][wm][1][lane]; hEr = ex[xb][wp][0][lane]; xb ^= 1;                       \
   }
   for (int it = 0; it < nsweep; it += 2) { SWEEPA(A, B) SWEEPA(B, A) }
   float r = errsum;
   for (int k = 0; k < R; k++) r += A[k];
-  out[blockIdx.x * 512 + tid] = r;
+  out[(blockIdx.x * 1024 + tid) % (256 * 512)] = r;
 }
 
 // ---- B: lanes along x, two columns per lane, 8 rows per wave -----------------------------------
@@ -188,7 +188,7 @@ int main() {
   const int nwg = 256, nsweep = 4000;
   float *in, *out;
   hipMalloc(&in, nwg * 512 * 16 * sizeof(float));
-  hipMalloc(&out, nwg * 512 * sizeof(float));
+  hipMalloc(&out, nwg * 1024 * sizeof(float));
   std::vector<float> h(nwg * 512 * 16);
   for (size_t i = 0; i < h.size(); i++) h[i] = 1e-3f * (float)((i * 2654435761u) % 1000) / 1000.f;
   hipMemcpy(in, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -196,10 +196,12 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   int clk = 0;
   hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-  const char* names[6] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
-                          "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell", "C  A0 with two sweeps per barrier (depth-2 halos)"};
+  const char* names[11] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
+                          "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell", "C  A0 with two sweeps per barrier (depth-2 halos)",
+                          "A0 with 16 waves x 8 columns", "A0 with 4 waves x 32 columns", "A0 with 12 waves x 11 columns (132 columns: x 0.97)",
+                          "A0 with 13 waves x 10 columns (130 columns)", "A0 with 10 waves x 13 columns (130 columns)"};
   for (int rep = 0; rep < 2; rep++)
-    for (int v = 0; v < 6; v++) {
+    for (int v = 0; v < 11; v++) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(sweepA<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 1) hipLaunchKernelGGL(sweepA<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
@@ -207,6 +209,11 @@ int main() {
       if (v == 3) hipLaunchKernelGGL(sweepA<3>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 4) hipLaunchKernelGGL(sweepB, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 5) hipLaunchKernelGGL(sweepC, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 6) hipLaunchKernelGGL((sweepA<0, 8, 16>), dim3(nwg), dim3(1024), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 7) hipLaunchKernelGGL((sweepA<0, 32, 4>), dim3(nwg), dim3(256), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 8) hipLaunchKernelGGL((sweepA<0, 11, 12>), dim3(nwg), dim3(768), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 9) hipLaunchKernelGGL((sweepA<0, 10, 13>), dim3(nwg), dim3(832), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 10) hipLaunchKernelGGL((sweepA<0, 13, 10>), dim3(nwg), dim3(640), 0, 0, out, in, nsweep, 0.25f);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms = 0; hipEventElapsedTime(&ms, e0, e1);
       if (rep) printf("%-45s %.0f ns per sweep = ~%.0f cycles at %.2f GHz (max clock)\n", names[v], ms * 1e6 / nsweep, ms * 1e6 / nsweep * (clk * 1e-6), clk * 1e-6);
