@@ -39,7 +39,7 @@ __device__ __forceinline__ float wave_sum63(float s) {
 // 2 = both neighbours by v_mov_dpp, then plain adds, 3 = (n + e) + (s + w) with two independent fused DPP adds
 template <int VAR>
 __device__ __forceinline__ float nsum(float e, float w, float c) {
-  if (VAR == 0) return add2dpp(e + w, c);
+  if (VAR == 0 || VAR >= 4) return add2dpp(e + w, c);
   if (VAR == 1) return (e + w) + dppf<0x130, 0xf>(c) + dppf<0x138, 0xf>(c);
   if (VAR == 2) { const float n = dppf<0x130, 0xf>(c), s = dppf<0x138, 0xf>(c); return (e + w) + (n + s); }
   return add_shl(e, c) + add_shr(w, c);
@@ -61,10 +61,11 @@ __global__ __launch_bounds__(NW * 64) void sweepA(float* out, const float* in, i
 #define CELLA(c, e, wv, nbk) (cx * nsum<VAR>(e, wv, c) + (cB * (c) + (nbk)))
 #define SWEEPA(S, D)                                                                     \
   {                                                                                      \
-    float acc = 0;                                                                       \
-    _Pragma("unroll") for (int k = 1; k < R - 1; k++) { float ph = CELLA(S[k], S[k + 1], S[k - 1], nb[k]); float d = ph - S[k]; acc += d * d; D[k] = ph; } \
-    const float pI = wl * acc;                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
+    float acc = 0, accb = 0;                                                             \
+    _Pragma("unroll") for (int k = 1; k < R - 1; k++) { float ph = CELLA(S[k], S[k + 1], S[k - 1], nb[k]); float d = ph - S[k]; \
+      if (VAR == 6) {} else if (VAR == 4 && (k & 1)) accb += d * d; else acc += d * d; D[k] = ph; } \
+    const float pI = wl * (acc + accb);                                                  \
+    if (VAR != 5) __builtin_amdgcn_sched_barrier(0);                                     \
     { _Pragma("unroll") for (int st = 1; st < NW; st *= 2) _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) e8[q] += e8[q + st]; \
       errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e8[0]), 0)); } \
     hW = (w > 0) ? hWr : S[0]; hE = (w < NW - 1) ? hEr : S[R - 1];                       \
@@ -196,12 +197,13 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   int clk = 0;
   hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-  const char* names[11] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
+  const char* names[14] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
                           "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell", "C  A0 with two sweeps per barrier (depth-2 halos)",
                           "A0 with 16 waves x 8 columns", "A0 with 4 waves x 32 columns", "A0 with 12 waves x 11 columns (132 columns: x 0.97)",
-                          "A0 with 13 waves x 10 columns (130 columns)", "A0 with 10 waves x 13 columns (130 columns)"};
+                          "A0 with 13 waves x 10 columns (130 columns)", "A0 with 10 waves x 13 columns (130 columns)",
+                          "A4 two residual accumulators", "A5 no sched_barrier", "A6 no interior residual (floor, wrong)"};
   for (int rep = 0; rep < 2; rep++)
-    for (int v = 0; v < 11; v++) {
+    for (int v = 0; v < 14; v++) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(sweepA<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 1) hipLaunchKernelGGL(sweepA<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
@@ -209,6 +211,9 @@ int main() {
       if (v == 3) hipLaunchKernelGGL(sweepA<3>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 4) hipLaunchKernelGGL(sweepB, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 5) hipLaunchKernelGGL(sweepC, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 11) hipLaunchKernelGGL(sweepA<4>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 12) hipLaunchKernelGGL(sweepA<5>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 13) hipLaunchKernelGGL(sweepA<6>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 6) hipLaunchKernelGGL((sweepA<0, 8, 16>), dim3(nwg), dim3(1024), 0, 0, out, in, nsweep, 0.25f);
       if (v == 7) hipLaunchKernelGGL((sweepA<0, 32, 4>), dim3(nwg), dim3(256), 0, 0, out, in, nsweep, 0.25f);
       if (v == 8) hipLaunchKernelGGL((sweepA<0, 11, 12>), dim3(nwg), dim3(768), 0, 0, out, in, nsweep, 0.25f);
