@@ -167,10 +167,12 @@ BCN_API int bcn_set_mask(bcn_env_t h, const uint8_t* mask_dev);
 BCN_API int bcn_get_stp(bcn_env_t h, int32_t* buf_host, void* stream);
 BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);
 /* Which kernel variant *_step uses: 0 = generic (any grid, fields in HBM/L2, Jacobi in LDS),
- * 1 = register-resident CDNA4 path where the grid has one (falls back to 0 otherwise).
- * Returns the variant actually selected. */
+ * 1 = register-resident CDNA4 path where the grid has one (default there; falls back to 0 otherwise):
+ * rayleigh 128x64 f32/f64, 50x50 f32/f64, 100x50 / 150x50 / 200x50 / 100x100 f32; mixing 100x100 f32.
+ * Results of the two variants agree to rounding (float64: 1e-9).  Returns the variant actually selected. */
 BCN_API int bcn_set_variant(bcn_env_t h, int variant);
-/* name of the kernel *_step launches (for profiles) */
+/* name of the kernel the last *_step dispatched, e.g. "ns2d_fast_sched" (before the first step: the
+ * variant's plain kernel); for profiles */
 BCN_API const char* bcn_kernel_name(bcn_env_t h);
 BCN_API int bcn_destroy(bcn_env_t h);
 BCN_API const char* bcn_last_error(void);
