@@ -751,6 +751,33 @@ def test_sloshing_vs_golden(dtype, tol):
     env.close()
 
 
+@pytest.mark.parametrize("L,nsteps", [(1.7, 6), (4.0, 4)])
+def test_sloshing_other_lengths_vs_oracle_f64(L, nsteps):
+    """Tank lengths other than the packaged one (nx = 80 L = 136 / 320: odd thread counts, two waves per
+    replica), started from a smooth synthetic free surface; float64 against the oracle."""
+    nx = int(80 * L)
+    x = (np.arange(nx + 2) - 0.5) / nx
+    init = np.zeros((2, nx + 2))
+    init[0] = 1.0 + 0.05 * np.cos(np.pi * x)
+    B = 3
+    rng = np.random.default_rng(int(10 * L))
+    acts = rng.uniform(-1, 1, (nsteps, B))
+    env = V.VecSloshing(B, DEV, "f64", init, L=L)
+    env.reset()
+    oracles = [O.sloshing(init_fields=init, L=L) for _ in range(B)]
+    for o in oracles:
+        o.reset()
+    for k in range(nsteps):
+        obs, rwd, done, _, _ = env.step(acts[k])
+        st = env.get_state().cpu().numpy()
+        for b, o in enumerate(oracles):
+            ob, rw, dn, _, _ = o.step([acts[k, b]])
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= 1e-12 and abs(float(rwd[b]) - rw) <= 1e-12
+            assert maxdiff(st[b][0], o.h) <= 1e-12 and maxdiff(st[b][1], o.q) <= 1e-12
+            assert bool(done[b]) == bool(dn)
+    env.close()
+
+
 def test_sloshing_blowup_flag():
     env = V.VecSloshing(2, DEV, "f64", None)
     env.reset()
