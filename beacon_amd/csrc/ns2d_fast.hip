@@ -42,9 +42,6 @@
 #ifndef BCN_R128D
 #define BCN_R128D 16   // columns per lane of the float64 128x64 kernel
 #endif
-#ifndef BCN_LAG
-#define BCN_LAG 0   // lagged convergence test: measured no faster (1556 vs 1555 cycles per sweep), kept for reference
-#endif
 
 #ifndef BCN_ERRB
 #define BCN_ERRB 1   // error norm across the workgroup: wave DPP reduction -> NW partials in LDS, then
@@ -362,67 +359,6 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #ifdef BCN_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
-#if BCN_LAG
-    // Lagged convergence test: phi rotates through THREE register arrays; the error norm of sweep
-    // n is reduced and published while sweep n+1 runs and is tested during sweep n+2, so the
-    // reduction chain and its LDS round trip are off the barrier-to-barrier critical path.  When
-    // the test passes, the array holding phi_n is still intact (at most ~1.75 sweeps are dropped)
-    // and `hW` still holds its west halo for the corrector.  Sweep counts are unchanged.
-    real phA[R], phB[R], phC[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) { phA[k] = 0; phB[k] = 0; phC[k] = 0; }
-    real accPrev = 0;               // weighted error partial of the previous sweep (per lane)
-    int nsw = 0;                    // sweeps started
-    int fin = 0;                    // which array holds the result
-#define BCN_SWEEP(SRC, DST, OLD_IDX)                                                         \
-    {                                                                                        \
-      nsw++;                                                                                 \
-      real acc = 0;                                                                          \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                    \
-        const real ph = cell(SRC[k], SRC[k + 1], SRC[k - 1], nb[k]);                         \
-        const real d = ph - SRC[k];                                                          \
-        acc += d * d;                                                                        \
-        DST[k] = ph;                                                                         \
-      }                                                                                      \
-      if (nsw >= 3) {                                                                        \
-        const real err = read_lane(row16_sum<real>(eL), 15);      /* of sweep nsw-2 */       \
-        itp = nsw - 2;                                                                       \
-        if (itp > A.itmax) { status |= BCN_ST_ITMAX; fin = OLD_IDX; break; }                 \
-        if (!(err > A.tol)) { fin = OLD_IDX; break; }                                        \
-      }                                                                                      \
-      if (nsw >= 2) {                                                                        \
-        hW = (w > 0) ? hWr : SRC[0];                                                         \
-        hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                \
-        const real tot63 = wave_sum_lane63<real>(accPrev);        /* of sweep nsw-1 */       \
-        if (lane == 63) errp[xb * 16 + w] = tot63;                                           \
-      }                                                                                      \
-      const real p0 = cell(SRC[0], SRC[1], hW, nb[0]);                                       \
-      const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
-      const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
-      DST[0] = p0;                                                                           \
-      DST[R - 1] = pl;                                                                       \
-      ex(xb, w, 0)[lane] = p0;                                                               \
-      ex(xb, w, 1)[lane] = pl;                                                               \
-      acc += d0 * d0;                                                                        \
-      acc += dl * dl;                                                                        \
-      accPrev = wl * acc + fW * (d0 * d0) + fE * (dl * dl);                                  \
-      __syncthreads();                                                                       \
-      eL = errp[xb * 16 + (lane & 15)];                                                      \
-      hWr = ex(xb, wm, 1)[lane];                                                             \
-      hEr = ex(xb, wp, 0)[lane];                                                             \
-      xb ^= 1;                                                                               \
-    }
-    for (;;) {
-      BCN_SWEEP(phA, phB, 2)
-      BCN_SWEEP(phB, phC, 0)
-      BCN_SWEEP(phC, phA, 1)
-    }
-#undef BCN_SWEEP
-    if (fin != 0) {
-#pragma unroll
-      for (int k = 0; k < R; k++) phA[k] = (fin == 1) ? phB[k] : phC[k];
-    }
-#else
     real phA[R], phB[R];
 #pragma unroll
     for (int k = 0; k < R; k++) phA[k] = 0;
@@ -495,7 +431,6 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #pragma unroll
       for (int k = 0; k < R; k++) phA[k] = phB[k];
     }
-#endif
 #ifdef BCN_STAMP   // diagnostic build only: cycles per sweep in the high half of the sweep count
     {
       const unsigned long long st1 = __builtin_amdgcn_s_memtime();
