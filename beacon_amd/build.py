@@ -26,7 +26,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=h
 
 # per-file flags.  ns2d_fast: the SLP vectoriser packs the Jacobi arithmetic into v_pk_* ops at the
 # price of many register shuffles -- measured slower than the scalar stream on gfx950.
-FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on"], "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on"]}
+FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on"], "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on"],
+              # float64 1D kernels: the reference's operation order without FMA contraction -> bit-identical fields
+              "env1d_f64.hip": ["-ffp-contract=off"]}
 
 
 def hipcc():
@@ -41,7 +43,8 @@ def sources():
 
 
 def _deps():
-    return sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
+    return (sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +
+            glob.glob(os.path.join(INC, "*.h")))
 
 
 def signature():

@@ -3,7 +3,7 @@
 for fl in "" "-fno-hip-fp32-correctly-rounded-divide-sqrt"; do
   python - <<PY || exit 1
 from beacon_amd import build
-build.FILE_FLAGS["env1d.hip"] = "$fl".split()
+build.FILE_FLAGS["env1d_f32.hip"] = "$fl".split()
 build.build_lib(force=True, verbose=False)
 PY
   echo "env1d flags: [$fl]"

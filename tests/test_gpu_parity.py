@@ -778,6 +778,45 @@ def test_sloshing_other_lengths_vs_oracle_f64(L, nsteps):
     env.close()
 
 
+def test_env1d_float64_bit_identical_to_oracle():
+    """The float64 1D kernels follow the reference's operation order and are built without FMA contraction
+    (env1d_f64.hip): fields and observations equal the oracle's -- which equals the reference bit for bit
+    (tests/test_oracle.py) -- EXACTLY; only the rewards, which are reductions, differ in the last bits."""
+    rng = np.random.default_rng(1)
+    env, o = V.VecBurgers(1, DEV, "f64"), O.burgers()
+    env.reset(); o.reset()
+    for k in range(20):
+        a, n = rng.uniform(-1, 1), rng.uniform(-0.1, 0.1)
+        obs, rwd, _, _, _ = env.step(np.array([a]), np.array([n]))
+        ob, rw, _, _, _ = o.step([a], n)
+        assert np.array_equal(env.get_state().cpu().numpy()[0, 0], o.u) and np.array_equal(obs[0].cpu().numpy(), ob)
+        assert abs(float(rwd[0]) - rw) <= 1e-13
+    env.close()
+    init = E.packaged_init("sloshing")
+    env, o = V.VecSloshing(1, DEV, "f64", init), O.sloshing(init_fields=init)
+    env.reset(); o.reset()
+    for k in range(20):
+        a = rng.uniform(-1, 1)
+        obs, rwd, _, _, _ = env.step(np.array([a]))
+        ob, rw, _, _, _ = o.step([a])
+        st = env.get_state().cpu().numpy()[0]
+        assert np.array_equal(st[0], o.h) and np.array_equal(st[1], o.q) and np.array_equal(obs[0].cpu().numpy(), ob)
+        assert abs(float(rwd[0]) - rw) <= 1e-13
+    env.close()
+    init = E.packaged_init("shkadov")
+    env, o = V.VecShkadov(1, DEV, "f64", init), O.shkadov(init_fields=init)
+    o.rand_init = False
+    env.reset(); o.reset()
+    for k in range(8):
+        a, nz = rng.uniform(-1, 1, 5), rng.uniform(-5e-4, 5e-4, 50)
+        obs, rwd, _, _, _ = env.step(a[None], nz[None])
+        ob, rw, _, _, _ = o.step(a.tolist(), nz)
+        st = env.get_state().cpu().numpy()[0]
+        assert np.array_equal(st[0], o.h) and np.array_equal(st[1], o.q) and np.array_equal(obs[0].cpu().numpy(), ob)
+        assert abs(float(rwd[0]) - rw) <= 1e-13
+    env.close()
+
+
 def test_sloshing_blowup_flag():
     env = V.VecSloshing(2, DEV, "f64", None)
     env.reset()
