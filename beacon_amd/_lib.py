@@ -85,6 +85,8 @@ SIGNATURES = {
     "bcn_get_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_variant": (C.c_int, [vp, C.c_int]),
+    "bcn_get_counters": (C.c_int, [vp, C.POINTER(C.c_uint64), vp]),
+    "bcn_set_sched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bcn_kernel_name": (C.c_char_p, [vp]),
     "bcn_destroy": (C.c_int, [vp]),
     "bcn_last_error": (C.c_char_p, []),
@@ -104,11 +106,17 @@ def load():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if _build.stale() and _build.hipcc() is not None:
+    if _build.stale():
+        # BEACON_NO_BUILD=1 (exported by the profiling scripts): never spawn a compiler from this process --
+        # under rocprofv3 the children would inherit the profiler's preload (scripts/prof_bench.sh).
+        # A stale binary is never dlopen'ed: its cfg structs / signatures may disagree with this source tree.
+        if os.environ.get("BEACON_NO_BUILD") == "1":
+            raise RuntimeError("libbeacon_hip.so is missing or stale and BEACON_NO_BUILD=1: run "
+                               "`python -c 'import __graft_entry__ as g; g.build()'` first")
+        if _build.hipcc() is None:
+            raise RuntimeError("libbeacon_hip.so is missing or older than its sources and hipcc is not "
+                               "available to build it; beacon_amd has no CPU fallback")
         path = _build.build_lib()
-    if not os.path.exists(path):
-        raise RuntimeError("libbeacon_hip.so is missing and hipcc is not available to build it; "
-                           "beacon_amd has no CPU fallback")
     L = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

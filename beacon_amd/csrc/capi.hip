@@ -34,7 +34,8 @@ struct NS2DEnv : bcn_env_s {
   NS2DArgs<real> a{};
   DevBuf fields;    // u,v,p,S,us,vs   [6][B][ncell]
   DevBuf work;      // g0,g1,g2        [3][B][ncell]  (only when the work arrays do not fit LDS)
-  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf, schedbuf, fscrbuf;
+  DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf, schedbuf, fscrbuf, statusbuf;
+  int32_t* status_int = nullptr;   // per-replica status words when the caller passes no status_dev
   bool fast_ok = false;
 
   int init() {
@@ -66,10 +67,19 @@ struct NS2DEnv : bcn_env_s {
     if ((rc = sweepbuf.alloc((size_t)batch * (a.ndt_act > 0 ? a.ndt_act : 1) * sizeof(int32_t)))) return rc;
     BCN_HIP(hipMemset(sweepbuf.p, 0, sweepbuf.bytes));
     a.sweeps_int = static_cast<int32_t*>(sweepbuf.p);
+    if ((rc = statusbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
+    BCN_HIP(hipMemset(statusbuf.p, 0, statusbuf.bytes));
+    status_int = static_cast<int32_t*>(statusbuf.p);
     if ((rc = orderbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
     a.order_out = static_cast<int32_t*>(orderbuf.p);
-    if ((rc = schedbuf.alloc(128 + (size_t)batch * sizeof(uint32_t)))) return rc;
-    a.sched_ctl = schedbuf.p;
+    {   // [ SchedCtl + progress[B] | pad to 16 | cyc[B][2] ]: zeroed by one memset per step
+      const size_t ctl = (128 + (size_t)batch * sizeof(uint32_t) + 15) / 16 * 16;
+      a.sched_bytes = ctl + (size_t)batch * 2 * sizeof(unsigned long long);
+      if ((rc = schedbuf.alloc(a.sched_bytes))) return rc;
+      BCN_HIP(hipMemset(schedbuf.p, 0, a.sched_bytes));
+      a.sched_ctl = schedbuf.p;
+      a.cyc = reinterpret_cast<unsigned long long*>(static_cast<char*>(schedbuf.p) + ctl);
+    }
     fast_ok = ns2d_fast_supported<real>(a);
     if (fast_ok && (a.fscr_stride = ns2d_fast_scratch_elems<real>(a)) > 0) {
       if ((rc = fscrbuf.alloc((size_t)batch * a.fscr_stride * sizeof(real)))) return rc;
@@ -82,7 +92,7 @@ struct NS2DEnv : bcn_env_s {
   ~NS2DEnv() override {
     DeviceGuard g(device);
     fields.release(); work.release(); fscrbuf.release(); obs_hist.release(); a_last.release(); ia_last.release();
-    stpbuf.release(); sweepbuf.release(); orderbuf.release(); schedbuf.release();
+    stpbuf.release(); sweepbuf.release(); orderbuf.release(); schedbuf.release(); statusbuf.release();
   }
   size_t state_elems() const override { return 4 * (size_t)a.ncell; }
   // state buffer layout: [B][4][ncell]; device layout: [4][B][ncell]
@@ -105,6 +115,15 @@ struct NS2DEnv : bcn_env_s {
   }
   int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; launched = nullptr; return variant; }
   void set_mask(const uint8_t* m) override { a.mask = m; }
+  int set_sched(int mode, int grid, int q, int lpt_min_batch) override {
+    a.sched_mode = mode; a.sched_grid = grid; a.sched_q_user = q; a.lpt_min_batch = lpt_min_batch;
+    return BCN_OK;
+  }
+  int get_counters(uint64_t* host, hipStream_t s) override {
+    BCN_HIP(hipMemcpyAsync(host, a.cyc, (size_t)batch * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    BCN_HIP(hipStreamSynchronize(s));
+    return BCN_OK;
+  }
   const char* launched = nullptr;   // name of the kernel the last step dispatched
   const char* kernel_name() const override {
     return launched ? launched : (variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step");
@@ -320,7 +339,8 @@ static int ns2d_step_t(bcn_env_t h, const void* actions, const int32_t* iactions
   a.actions_norm = static_cast<real*>(actions_norm);
   a.obs_out = static_cast<real*>(obs);
   a.rwd_out = static_cast<real*>(rwd);
-  a.done = done; a.trunc = trunc; a.status = status; a.sweeps = sweeps;
+  a.done = done; a.trunc = trunc; a.sweeps = sweeps;
+  a.status = status ? status : e->status_int;   // the chunk scheduler carries a replica's status across chunks
   return e->launch(static_cast<hipStream_t>(stream));
 }
 
@@ -517,6 +537,16 @@ int bcn_set_mask(bcn_env_t h, const uint8_t* mask_dev) {
   return BCN_OK;
 }
 int bcn_set_variant(bcn_env_t h, int variant) { return h ? h->set_variant(variant) : 0; }
+int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream) {
+  if (!h || !buf_host) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
+  DeviceGuard g(h->device);
+  return h->get_counters(buf_host, static_cast<hipStream_t>(stream));
+}
+int bcn_set_sched(bcn_env_t h, int mode, int grid, int q, int lpt_min_batch) {
+  if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }
+  if (mode < -1 || mode > 2 || grid < 0 || q < 0 || lpt_min_batch < 0) { bcn_set_error("bcn_set_sched: argument out of range"); return BCN_ERR_ARG; }
+  return h->set_sched(mode, grid, q, lpt_min_batch);
+}
 const char* bcn_kernel_name(bcn_env_t h) { return h ? h->kernel_name() : ""; }
 int bcn_destroy(bcn_env_t h) {
   if (!h) return BCN_OK;

@@ -47,8 +47,12 @@ struct NS2DArgs {
   const int32_t* order;     // blockIdx -> replica, or NULL for identity
   int32_t* order_out;       // rank kernel output
   int32_t* sweeps_int;      // handle-owned [B][ndt_act] when the caller passes no sweeps buffer
-  void* sched_ctl;          // handle-owned control block of the ticketed chunk scheduler (64 + 4B bytes)
+  void* sched_ctl;          // handle-owned control block of the ticketed chunk scheduler (64 + 4B bytes), followed by
+  unsigned long long* cyc;  // [B][2] shader-clock cycles of the last step: inside the Jacobi loop / whole replica (bcn_get_counters)
+  size_t sched_bytes;       // bytes of sched_ctl + cyc: zeroed by one memset in front of every step launch
   int sched_q;              // timesteps per chunk
+  int sched_mode = -1;      // per-handle overrides of the BCN_SCHED* defaults (bcn_set_sched): -1 / 0 = default
+  int sched_grid = 0, sched_q_user = 0, lpt_min_batch = 0;
   const char** launched;    // host side: receives the name of the kernel the launcher dispatched (may be NULL)
   real* fscr;               // per-workgroup field scratch of the register-resident kernels whose u, v, T do not
   size_t fscr_stride;       //   fit LDS (float64 128x64): [slots][fscr_stride] elements, slot = workgroup index

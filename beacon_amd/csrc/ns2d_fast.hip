@@ -234,7 +234,9 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #else
 #define BCN_PH(x)
 #endif
-  if (!first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
+  if (!first_chunk) status = A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
+  const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
+  unsigned long long cyc_j = 0;
   for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
@@ -332,6 +334,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     }
 
     BCN_PH(1)
+    const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
     // ---- Jacobi sweeps (rayleigh.py:419-454): one barrier per sweep --------------------------
     // phi ping-pongs between two register arrays (two sweeps per loop trip, no copies).  After
     // the barrier the LDS reads (error partials, strip-edge halos) are issued first and the
@@ -441,6 +444,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 #endif
 
+    cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
     BCN_PH(2)
     // ---- p += phi (rayleigh.py:219), corrector (rayleigh.py:460-464) -> LDS u, v --------------
 #pragma unroll
@@ -521,8 +525,12 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #endif
   if (last_chunk) {
     ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
-  } else if (tid == 0 && A.status) {
+  } else if (tid == 0) {
     A.status[b] = status;
+  }
+  if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
+    A.cyc[2 * (size_t)b] += cyc_j;
+    A.cyc[2 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
   }
 }
 
@@ -583,7 +591,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
-  const SchedParams& sp = ns2d_sched_params();
+  const SchedParams sp = ns2d_sched_params(a);
   const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
     auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ, GF>;
@@ -593,25 +601,19 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     }
     const int nchunk = a.ndt_act / SQ;
     c.sched_q = SQ; c.order = nullptr; c.first_chunk = 1; c.last_chunk = 1; c.it_begin = 0; c.it_end = a.ndt_act;
-    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, sizeof(SchedCtl) + (size_t)batch * sizeof(unsigned int), s));
+    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
     hipLaunchKernelGGL(ks, dim3(sched_grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
     BCN_HIP(hipGetLastError());
     if (a.launched) *a.launched = "ns2d_fast_sched";
     return BCN_OK;
   }
   // split only when replicas outnumber the CUs (otherwise every replica starts at once and
-  // the order cannot matter); BCN_LPT_MIN_BATCH overrides the threshold (tests)
-  static int min_batch = -1;
-  if (min_batch < 0) {
-    const char* e = getenv("BCN_LPT_MIN_BATCH");
-    int dev = 0, ncu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    min_batch = e ? atoi(e) : ncu + 1;
-  }
+  // the order cannot matter); BCN_LPT_MIN_BATCH / bcn_set_sched override the threshold (tests)
+  const int min_batch = sp.lpt_min_batch;
   constexpr int Q = 10;
   const bool split = mode >= 1 && batch >= min_batch && batch <= 2048 && a.ndt_act >= 4 * Q;
   c.first_chunk = 1; c.order = nullptr; c.it_begin = 0;
+  if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
   if (!split) {
     c.it_end = a.ndt_act; c.last_chunk = 1;
     hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);

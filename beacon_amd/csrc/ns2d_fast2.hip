@@ -192,7 +192,9 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #else
 #define BCN_PH(x)
 #endif
-  if (!first_chunk && A.status) status = A.status[b];   // a replica that overflowed stays stopped
+  if (!first_chunk) status = A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
+  const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
+  unsigned long long cyc_j = 0;
   for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202 / mixing.py:153-171) ------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
@@ -304,6 +306,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     }
 
     BCN_PH(1)
+    const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
     // ---- Jacobi sweeps: one barrier per sweep, phi ping-pong in registers ---------------------
     real phA[2][RW], phB[2][RW];
 #pragma unroll
@@ -406,6 +409,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     }
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 
+    cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
     BCN_PH(2)
     // ---- p += phi, corrector: u = u* - dt dphi/dx, v = v* - dt dphi/dy (in place in LDS) -------
 #pragma unroll
@@ -484,8 +488,12 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   __syncthreads();
   if (last_chunk) {
     ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
-  } else if (tid == 0 && A.status) {
+  } else if (tid == 0) {
     A.status[b] = status;
+  }
+  if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
+    A.cyc[2 * (size_t)b] += cyc_j;
+    A.cyc[2 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
   }
 #ifdef BCN_STAMP   // diagnostic build only: cycles per timestep of each phase over the first obs entries
   __syncthreads();
@@ -533,7 +541,7 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   const size_t lds = G::lds_elems() * sizeof(real);
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
-  const SchedParams& sp = ns2d_sched_params();
+  const SchedParams sp = ns2d_sched_params(a);
   const int q = sp.q_set ? sp.q : 20;   // 100x100: 20 timesteps per chunk measured best (37.7 vs 38.2 ms at 10)
   if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * q && a.sched_ctl) {
     auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ>;
@@ -541,12 +549,13 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     if (ns2d_first_on_device(set2)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nchunk = a.ndt_act / q;
     c.sched_q = q;
-    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, sizeof(SchedCtl) + (size_t)batch * sizeof(unsigned int), s));
+    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
     hipLaunchKernelGGL(ks, dim3(sp.grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
     BCN_HIP(hipGetLastError());
     if (a.launched) *a.launched = "ns2d_fast2_sched";
     return BCN_OK;
   }
+  if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
   auto k = ns2d_fast2_step<real, NX, NY, R, KIND, EQ>;
   static unsigned long long set = 0;
   if (ns2d_first_on_device(set)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -65,8 +65,8 @@ __device__ __forceinline__ void ns2d_sched_loop(const NS2DArgs<real>& A, SchedCt
         const int it0 = c * A.sched_q;
         const int it1 = (c == nchunk - 1) ? A.ndt_act : it0 + A.sched_q;
         unit(b, it0, it1, c == 0, c == nchunk - 1);
-      } else if (threadIdx.x == 0 && A.status) {
-        A.status[b] = BCN_ST_ITMAX;
+      } else if (threadIdx.x == 0) {
+        A.status[b] = BCN_ST_ITMAX;   // handle-owned when the caller passed none: never NULL here
       }
       __syncthreads();   // every wave's stores are issued and waited for (barrier implies vmcnt(0))
       if (threadIdx.x == 0) {
@@ -91,23 +91,45 @@ inline bool ns2d_first_on_device(unsigned long long& seen) {
 }
 
 // host side: BCN_SCHED = 0 plain launch, 1 two-launch LPT split (ns2d_fast only), 2 ticketed chunks
-// (default); BCN_SCHED_GRID persistent workgroups (default: one per CU); BCN_SCHED_Q timesteps per chunk
+// (default); BCN_SCHED_GRID persistent workgroups (default: one per CU of the handle's device); BCN_SCHED_Q
+// timesteps per chunk.  The environment gives the process-wide defaults; bcn_set_sched() overrides them per
+// handle (NS2DArgs::sched_mode / sched_grid / sched_q_user, -1 / 0 / 0 = default).
 struct SchedParams {
   int mode, grid, q;
-  bool q_set;   // BCN_SCHED_Q given: overrides the per-kernel default
+  bool q_set;   // chunk length given (environment or handle): overrides the per-kernel default
+  int lpt_min_batch;
 };
-inline const SchedParams& ns2d_sched_params() {
-  static SchedParams p = {-1, 0, 10, false};
-  if (p.mode < 0) {
+inline int ns2d_cu_count() {   // of the current device (one handle per device; a process may hold several)
+  static int ncu[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& n = ncu[dev & 63];
+  if (n <= 0) {
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  return n;
+}
+template <typename real>
+inline SchedParams ns2d_sched_params(const NS2DArgs<real>& a) {
+  static int env_mode = -2, env_grid = 0, env_q = 0, env_lpt = 0;
+  if (env_mode == -2) {
     const char* e = getenv("BCN_SCHED");
     const char* g = getenv("BCN_SCHED_GRID");
     const char* q = getenv("BCN_SCHED_Q");
-    if (q && atoi(q) > 0) { p.q = atoi(q); p.q_set = true; }
-    int dev = 0, ncu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    p.grid = g ? atoi(g) : ncu;
-    p.mode = e ? atoi(e) : 2;
+    const char* l = getenv("BCN_LPT_MIN_BATCH");
+    env_grid = g ? atoi(g) : 0;
+    env_q = (q && atoi(q) > 0) ? atoi(q) : 0;
+    env_lpt = l ? atoi(l) : 0;
+    env_mode = e ? atoi(e) : 2;
   }
+  SchedParams p;
+  p.mode = a.sched_mode >= 0 ? a.sched_mode : env_mode;
+  const int ncu = ns2d_cu_count();
+  p.grid = a.sched_grid > 0 ? a.sched_grid : (env_grid > 0 ? env_grid : ncu);
+  const int q = a.sched_q_user > 0 ? a.sched_q_user : env_q;
+  p.q_set = q > 0;
+  p.q = q > 0 ? q : 10;
+  p.lpt_min_batch = a.lpt_min_batch > 0 ? a.lpt_min_batch : (env_lpt > 0 ? env_lpt : ncu + 1);
   return p;
 }

@@ -1,12 +1,15 @@
 """Multi-GPU replica sharding: replicas are independent, so the env batch is
 partitioned by replica index -- rank r owns global replicas [r*B_local, (r+1)*B_local) -- with NO
 data-path collective inside the solver.  The only exchange per step() is the trainer-facing one:
-rank 0 scatters actions[B_global, n_act] and gathers obs / rwd / done / trunc / status, over
-torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+rank 0 scatters actions[B_global, n_act] and gathers the packed per-step outputs (obs, rwd, status,
+done, trunc: ONE byte buffer per rank, ONE collective) over torch.distributed (backend "nccl" == RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
 
-One process per GPU; messages are <= ~100 KB per rank per step, i.e. latency-bound."""
+One process per GPU; the message is ~100-800 KB per rank per step, i.e. latency-bound."""
 import torch
 import torch.distributed as dist
+
+from .vec import unpack_outputs
 
 
 def shard_bounds(n_global, world, rank):
@@ -43,12 +46,13 @@ class ReplicaSharder(object):
         return out
 
     def gather(self, name, local):
-        """Gather one per-replica tensor to rank 0 -> [B_global, ...] there, None elsewhere.
+        """Gather one per-replica tensor to rank 0 -> [world, ...local.shape] there, None elsewhere.
         Receive buffers are allocated once per name and reused."""
         if self.world == 1:
-            return local
+            return local.unsqueeze(0)
         local = local.contiguous()
         bufs = None
+        full = None
         if self.rank == 0:
             key = (name, tuple(local.shape), local.dtype, str(local.device))
             if key not in self._bufs:
@@ -57,9 +61,19 @@ class ReplicaSharder(object):
             full = self._bufs[key]
             bufs = list(full.unbind(0))
         dist.gather(local, bufs, dst=0, group=self.group)
-        if self.rank == 0:
-            return full.reshape((self.global_batch,) + tuple(local.shape[1:]))
-        return None
+        return full
+
+    def gather_outputs(self, out_buf, obs_dim, tdtype):
+        """ONE collective per step: every rank's packed output buffer (vec.out_layout) to rank 0, which
+        returns (obs[B_global, n], rwd, status, done, trunc) assembled from the per-rank segments;
+        other ranks return None."""
+        full = self.gather("out", out_buf)
+        if full is None:
+            return None
+        parts = [unpack_outputs(full[r], self.local_batch, obs_dim, tdtype) for r in range(full.shape[0])]
+        if len(parts) == 1:
+            return parts[0]
+        return tuple(torch.cat([p[k] for p in parts], dim=0) for k in range(5))
 
 
 class ShardedVecEnv(object):
@@ -68,13 +82,17 @@ class ShardedVecEnv(object):
         env = ShardedVecEnv(VecRayleigh(B_local, device=f"cuda:{local_rank}", ...))
         obs, _ = env.reset()                       # rank 0: [B_global, n_obs]; other ranks: None
         obs, rwd, done, trunc, _ = env.step(actions_global_or_None_on_other_ranks)
-    """
 
-    def __init__(self, local_env, group=None):
+    Envs that draw inlet noise on the device (burgers, shkadov) are re-seeded with seed + global replica
+    offset, so that replica i of different ranks does not receive the same noise stream."""
+
+    def __init__(self, local_env, group=None, seed=0):
         self.env = local_env
         self.sh = ReplicaSharder(local_env.batch, group)
         self.global_batch = self.sh.global_batch
         self.lo, self.hi = shard_bounds(self.global_batch, self.sh.world, self.sh.rank)
+        if getattr(local_env, "gen", None) is not None:
+            local_env.gen.manual_seed(int(seed) + self.lo)
 
     def _like_actions(self):
         e = self.env
@@ -83,9 +101,14 @@ class ShardedVecEnv(object):
         shape = (e.batch,) if e.n_actions == 1 else (e.batch, e.n_actions)
         return torch.empty(shape, dtype=e.tdtype, device=e.device)
 
+    def _gather(self):
+        e = self.env
+        return self.sh.gather_outputs(e.out_buf, e.obs_dim, e.tdtype)
+
     def reset(self):
-        obs, _ = self.env.reset()
-        return self.sh.gather("obs", obs), None
+        self.env.reset()
+        g = self._gather()
+        return (g[0] if g is not None else None), None
 
     def step(self, actions_global=None, noise=None, scattered=False):
         """actions_global: full [B_global, ...] on rank 0 (ignored elsewhere) unless
@@ -94,12 +117,16 @@ class ShardedVecEnv(object):
             local = actions_global
         else:
             local = self.sh.scatter_actions(actions_global, self._like_actions())
-        obs, rwd, done, trunc, _ = self.env.step(local, noise)
-        return (self.sh.gather("obs", obs), self.sh.gather("rwd", rwd), self.sh.gather("done", done),
-                self.sh.gather("trunc", trunc), None)
+        self.env.step(local, noise)
+        g = self._gather()
+        if g is None:
+            return None, None, None, None, None
+        obs, rwd, self.status, done, trunc = g
+        return obs, rwd, done, trunc, None
 
     def gather_status(self):
-        return self.sh.gather("status", self.env.status)
+        """Status words of the last step() on rank 0 (they travel with the packed outputs)."""
+        return getattr(self, "status", None)
 
     def close(self):
         self.env.close()

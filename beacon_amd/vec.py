@@ -40,6 +40,31 @@ class Discrete(object):
         return int(rng.integers(0, self.n))
 
 
+def out_layout(batch, obs_dim, esz):
+    """Byte offsets of the packed per-step outputs of `batch` replicas."""
+    def up(x):
+        return (x + 15) // 16 * 16
+    o_obs = 0
+    o_rwd = up(o_obs + batch * obs_dim * esz)
+    o_status = up(o_rwd + batch * esz)
+    o_done = up(o_status + batch * 4)
+    o_trunc = up(o_done + batch)
+    return {"obs": o_obs, "rwd": o_rwd, "status": o_status, "done": o_done, "trunc": o_trunc,
+            "bytes": up(o_trunc + batch)}
+
+
+def unpack_outputs(buf, batch, obs_dim, tdtype):
+    """Typed views (obs[B, n], rwd[B], status[B] int32, done[B] u8, trunc[B] u8) of one packed byte buffer."""
+    esz = torch.empty((), dtype=tdtype).element_size()
+    lay = out_layout(batch, obs_dim, esz)
+    obs = buf[lay["obs"]:lay["obs"] + batch * obs_dim * esz].view(tdtype).view(batch, obs_dim)
+    rwd = buf[lay["rwd"]:lay["rwd"] + batch * esz].view(tdtype)
+    status = buf[lay["status"]:lay["status"] + batch * 4].view(torch.int32)
+    done = buf[lay["done"]:lay["done"] + batch]
+    trunc = buf[lay["trunc"]:lay["trunc"] + batch]
+    return obs, rwd, status, done, trunc
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -65,12 +90,17 @@ class VecEnv(object):
         self._create()
         self.obs_dim = self.lib.bcn_n_obs(self.h)       # observation length per replica
         self.n_actions = self.lib.bcn_n_act(self.h)
-        B = self.batch
-        self.obs = torch.zeros((B, self.obs_dim), dtype=self.tdtype, device=self.device)
-        self.rwd = torch.zeros((B,), dtype=self.tdtype, device=self.device)
-        self.done = torch.zeros((B,), dtype=torch.uint8, device=self.device)
-        self.trunc = torch.zeros((B,), dtype=torch.uint8, device=self.device)
-        self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self._alloc_outputs()
+
+    def _alloc_outputs(self):
+        """Per-step outputs live in ONE byte buffer [obs | rwd | status | done | trunc] (segments 16-byte
+        aligned), so the trainer-facing gather of a sharded batch is a single collective on `out_buf`
+        (beacon_amd/dist.py); obs / rwd / ... are typed views of it."""
+        B, esz = self.batch, torch.empty((), dtype=self.tdtype).element_size()
+        self.out_layout = out_layout(B, self.obs_dim, esz)
+        self.out_buf = torch.zeros((self.out_layout["bytes"],), dtype=torch.uint8, device=self.device)
+        v = unpack_outputs(self.out_buf, B, self.obs_dim, self.tdtype)
+        self.obs, self.rwd, self.status, self.done, self.trunc = v
 
     # -- plumbing ---------------------------------------------------------------------------
     def _stream(self):
@@ -122,6 +152,17 @@ class VecEnv(object):
 
     def set_variant(self, v):
         return self.lib.bcn_set_variant(self.h, int(v))
+
+    def set_sched(self, mode=-1, grid=0, q=0, lpt_min_batch=0):
+        """Scheduling of the register-resident 2D kernels (include/beacon_hip.h: bcn_set_sched);
+        results do not depend on it."""
+        _lib.check(self.lib.bcn_set_sched(self.h, int(mode), int(grid), int(q), int(lpt_min_batch)))
+
+    def get_counters(self):
+        """uint64 [B, 2]: shader cycles of the last step inside the Jacobi loop / in the whole replica."""
+        buf = (C.c_uint64 * (2 * self.batch))()
+        _lib.check(self.lib.bcn_get_counters(self.h, buf, self._stream()))
+        return np.frombuffer(buf, dtype=np.uint64).reshape(self.batch, 2).copy()
 
     @property
     def kernel_name(self):

@@ -1,36 +1,92 @@
 #!/usr/bin/env python3
-"""Headline benchmark: aggregate env steps/s of rayleigh-v0 (128x64 grid, batch 512 per GPU).
+"""Headline benchmark: aggregate env steps/s of rayleigh-v0 (BASELINE configs[3]: 128x64 grid, batch 512).
 
-    python bench.py --gpus 1 --steps 20 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One "step" = one batched env.step(): 200 solver timesteps (BCs, predictor, Jacobi pressure
-Poisson to the reference's tolerance, corrector, ordered scalar transport) + obs + reward for
-every replica, in ONE HIP launch per GPU; with N > 1 the per-step gather of obs/rwd/done to
-rank 0 (RCCL) is inside the timed region.  Weak scaling: 512 replicas per GPU.
-Inputs are synthetic and resident in HBM before the timed region: developed-flow initial
-state from tests/golden/rayleigh_128x64_init.npz (float64 oracle warm-up), actions from
-numpy.random.default_rng(1234 + rank).uniform(-1, 1), distinct per replica and step.
+N > 1 without a launcher: this process touches no GPU and starts N children (one per GPU, env RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT); under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` the ranks are used as launched.  One process per GPU, RCCL
+("nccl") only for the trainer-facing gather.
+
+One "step" = one batched env.step(): 200 solver timesteps (BCs, predictor, Jacobi pressure Poisson to the
+reference's tolerance, corrector, ordered scalar transport) + obs + reward for every replica, in ONE HIP
+launch per GPU; with N > 1 the per-step gather of the packed outputs (obs, rwd, status, done, trunc: one
+collective) to rank 0 is inside the timed region.
+  --scaling weak   (default) 512 replicas PER GPU                     -> "scaling": "weak"
+  --scaling strong the global batch of 512 sharded, 512/N per GPU     -> "scaling": "strong"
+Inputs are synthetic and resident in HBM before the timed region: developed-flow initial state from
+tests/golden/rayleigh_128x64_init.npz (float64 oracle warm-up), actions from
+numpy.random.default_rng(1234).uniform(-1, 1, (steps, global batch, 10)), distinct per replica and step.
 Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+N_CU, SIMD_PER_CU, CLK_HZ = 256, 4, 2.4e9
+VALU_ISSUE_PEAK = N_CU * SIMD_PER_CU * CLK_HZ / 2.0   # wave64 VALU instructions/s: one per 2 cycles per SIMD-32
+MIN_VALU_PER_CELL_SWEEP = 7      # e+w, +n, +s, ghost fma, cx fma, difference, residual fma
 
 
-def measured_traffic(kernel_name):
-    """HBM bytes per step() from the committed rocprofv3 PMC passes (scripts/prof_bench.sh ->
-    profiles/*_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, (2*FETCH + WRITE)*1024 as the
-    MI355X guide prescribes for gfx950), summed over the dispatches of one step.  None if absent."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="replicas per GPU (weak) / global batch (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--variant", type=int, default=-1, help="-1 = best available, 0 = generic kernel")
+    ap.add_argument("--sched", type=int, default=-1, help="scheduler mode of the fast kernels (bcn_set_sched)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations")
+    ap.add_argument("--zero-actions", action="store_true",
+                    help="diagnostic: uncontrolled steady flow (1 Jacobi sweep per timestep) -> non-Poisson cost")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --stub)")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU stand-in env (no GPU, no kernels): exercises launcher, sharding and gather only; "
+                         "its line is marked data=stub and is not a measurement")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# self-launch: the parent never touches the GPU (no torch import, no HIP call)
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_children(n, argv):
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# accounting
+# ------------------------------------------------------------------------------------------------
+def committed_profile(kernel_name, key):
+    """Per-dispatch counters from the committed rocprofv3 PMC passes (profiles/*_summary.json, produced by
+    scripts/prof.sh: separate --pmc passes; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide
+    prescribes for gfx950).  Latest file wins; None if absent."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
@@ -39,39 +95,37 @@ def measured_traffic(kernel_name):
         except Exception:
             continue
         for name, c in d.get("pmc", {}).items():
-            if name.startswith(kernel_name[:9]) and "hbm_bytes_per_dispatch" in c and "reset" not in name:
-                calls = d.get("kernels", {}).get(name, {}).get("calls")
-                n = c["FETCH_SIZE"]["dispatches"]
-                steps = d.get("bench_steps_incl_warmup", 6)
-                best = {"bytes_per_step": c["hbm_bytes_per_dispatch"] * n / steps, "source": os.path.basename(f)}
+            if name.startswith(kernel_name) and key in c and "reset" not in name:
+                best = {"value": c[key], "source": os.path.basename(f), "sweeps_per_dispatch": c.get("sweeps_per_dispatch")}
     return best
 
 
 def algorithmic_bytes(nx, ny, sweeps, esz):
     """per interior cell 20 values per timestep + 3 values per Jacobi sweep."""
     cells = nx * ny
-    ndt = sweeps.shape[1]
-    return float(cells) * esz * (20.0 * ndt * sweeps.shape[0] + 3.0 * float(sweeps.sum()))
+    return float(cells) * esz * (20.0 * sweeps.shape[1] * sweeps.shape[0] + 3.0 * float(sweeps.sum()))
 
 
-def cpu_baseline(init, acts, cfg_kw, seconds=15.0):
-    """The float64 scalar-C oracle ("port" of the reference's numba loops) on a bounded sample:
-    one env per host core, as many action steps as fit ~`seconds`."""
+def cpu_legs(state0, acts, cfg_kw, seconds=14.0):
+    """CPU baselines on a bounded sample of the SAME work the GPU timed: the first `cores` replicas, starting
+    from the GPU's state after the warm-up steps, with the actions of the first timed steps.
+      port : the float64 scalar-C oracle (restatement of the reference's numba loops), OpenMP over envs
+      numpy: the vectorised-NumPy restatement (oracle/numpy_port.py), one env on one core"""
     import ctypes as C
+    import numpy as np
     from oracle import oracle as O
+    from oracle import numpy_port as NP
     cores = os.cpu_count() or 1
-    nenv = min(cores, acts.shape[1])
+    nenv = min(cores, state0.shape[0])
     e = O.rayleigh(init=False, **cfg_kw)
     n = (e.cfg.nx + 2) * (e.cfg.ny + 2)
     st = np.zeros((nenv, 8, n))
-    st[:, :4] = init.reshape(1, 4, n)
-    nobs = e.n_obs_tot
-    obs = np.zeros((nenv, nobs))
+    st[:, :4] = np.swapaxes(state0[:nenv], -1, -2).reshape(nenv, 4, n)      # device [j][i] -> reference [i][j]
+    obs = np.zeros((nenv, e.n_obs_tot))
     rwd = np.zeros(nenv)
     sw = np.zeros(nenv, dtype=np.int64)
     L = O.lib()
-    done_steps, t0 = 0, time.perf_counter()
-    tot_sw = 0
+    done_steps, tot_sw, t0 = 0, 0, time.perf_counter()
     while done_steps < acts.shape[0]:
         a = np.ascontiguousarray(acts[done_steps, :nenv].astype(np.float64))
         L.orc_ns2d_step_batch(C.byref(e.cfg), nenv, O.dp(st.reshape(-1)), O.dp(a.reshape(-1)), a.shape[1],
@@ -81,114 +135,306 @@ def cpu_baseline(init, acts, cfg_kw, seconds=15.0):
         if time.perf_counter() - t0 > seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": nenv * done_steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d action steps of the same workload (float64 C oracle, OpenMP over envs, "
-                      "%.1f s, %.1f Jacobi sweeps per timestep)" % (nenv, done_steps, dt,
-                                                                   tot_sw / max(1, nenv * done_steps * e.cfg.ndt_act))}
+    port = {"value": nenv * done_steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "replicas 0..%d x the first %d timed action steps of the GPU run, from the GPU's state after "
+                      "warm-up (float64 C oracle, OpenMP over envs, %.1f s, %.1f Jacobi sweeps per timestep)"
+                      % (nenv - 1, done_steps, dt, tot_sw / max(1, nenv * done_steps * e.cfg.ndt_act))}
+    # vectorised NumPy, one env, one core: a fraction of one action step (whole timesteps) bounded by `seconds`
+    env = NP.Rayleigh(init_fields=np.swapaxes(state0[0], -1, -2), **cfg_kw)
+    t0, ndt, nsw = time.perf_counter(), 0, 0
+    a = NP.condition_actions(acts[0, 0].astype(np.float64), env.C)
+    while ndt < env.ndt_act:
+        nsw += env.timestep(a)
+        ndt += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    port["numpy"] = {"value": (ndt / env.ndt_act) / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
+                     "sample": "replica 0, first %d of %d timesteps of the first timed action step (vectorised "
+                               "NumPy restatement, 1 core, %.1f s, %.1f sweeps per timestep)"
+                               % (ndt, env.ndt_act, dt, nsw / max(1, ndt))}
+    return port
+
+
+# ------------------------------------------------------------------------------------------------
+# stub env: CPU tensors, same surface (launcher / sharding test on machines without a GPU)
+# ------------------------------------------------------------------------------------------------
+class StubEnv(object):
+    action_is_int = False
+
+    def __init__(self, batch):
+        import torch
+        from beacon_amd.vec import unpack_outputs, out_layout
+        self.batch, self.obs_dim, self.n_actions, self.n_sgts = batch, 8, 10, 10
+        self.tdtype, self.device = torch.float32, torch.device("cpu")
+        self.nx, self.ny, self.ndt_act, self.kernel_name = 4, 4, 2, "stub"
+        self.out_buf = torch.zeros((out_layout(batch, 8, 4)["bytes"],), dtype=torch.uint8)
+        self.obs, self.rwd, self.status, self.done, self.trunc = unpack_outputs(self.out_buf, batch, 8, self.tdtype)
+        self.sweeps = torch.ones((batch, 2), dtype=torch.int32)
+
+    def reset(self):
+        self.obs.zero_()
+        return self.obs, None
+
+    def step(self, a, noise=None):
+        self.obs[:] = a[:, :8] * 2
+        self.rwd[:] = a.sum(1)
+        return self.obs, self.rwd, self.done, self.trunc, None
+
+    def check_status(self):
+        return self.status
+
+    def get_counters(self):
+        import numpy as np
+        return np.ones((self.batch, 2), dtype=np.uint64)
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+def secondary_lines(dev, quick_steps=4):
+    """Other configurations of BASELINE.json on this GPU, one short measurement each (HIP events around
+    the launch, inputs resident): value = env steps/s, roofline per SURVEY 8d accounting."""
+    import numpy as np
+    import torch
+    from beacon_amd import vec as V
+    from beacon_amd.envs import packaged_init
+    out = []
+
+    def timed(env, step, n, warm=2):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for s, e in ev:
+            s.record()
+            step()
+            e.record()
+        torch.cuda.synchronize()
+        env.check_status()
+        return float(np.mean([s.elapsed_time(e) for s, e in ev]))
+
+    def line(name, env, ms, alg_bytes, extra=None):
+        d = {"workload": name, "value": env.batch / (ms * 1e-3), "unit": "env steps/s", "ms_per_launch": ms,
+             "kernel": env.kernel_name, "dtype": "f64" if env.tdtype == torch.float64 else "f32",
+             "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        d.update(extra or {})
+        out.append(d)
+
+    rng = np.random.default_rng(7)
+    # rayleigh 128x64 float64 (the reference's arithmetic), B=512
+    z = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))
+    env = V.VecRayleigh(512, dev, "f64", z["fields"], L=2.56, H=1.28)
+    env.reset()
+    acts = torch.as_tensor(rng.uniform(-1, 1, (8, 512, 10)), dtype=env.tdtype, device=dev)
+    k = [0]
+
+    def st():
+        env.step(acts[k[0] % 8]); k[0] += 1
+    ms = timed(env, st, quick_steps, warm=1)
+    line("rayleigh-v0 128x64 B=512 float64", env, ms, algorithmic_bytes(128, 64, env.sweeps.cpu().numpy(), 8),
+         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+    env.close()
+    # mixing 100x100 B=512 (configs[4])
+    env = V.VecMixing(512, dev, "f32")
+    env.reset()
+    ai = torch.as_tensor(rng.integers(0, 4, (8, 512)), dtype=torch.int32, device=dev)
+    k = [0]
+
+    def st():
+        env.step(ai[k[0] % 8]); k[0] += 1
+    ms = timed(env, st, quick_steps, warm=2)
+    line("mixing-v0 100x100 B=512 float32 (configs[4])", env, ms,
+         algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 4),
+         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+    env.close()
+    # burgers N=512 B=1024 (configs[1]): 12 B per cell per timestep
+    env = V.VecBurgers(1024, dev, "f32", nx=512)
+    env.reset()
+    a1 = torch.as_tensor(rng.uniform(-1, 1, (1024,)), dtype=env.tdtype, device=dev)
+    ms = timed(env, lambda: env.step(a1), 50, warm=5)
+    line("burgers-v0 N=512 B=1024 float32 (configs[1])", env, ms, 12.0 * 512 * env.ndt_act * 1024)
+    env.close()
+    # shkadov N=4096 10 jets B=1024 (configs[2]): 32 B per cell per timestep
+    env = V.VecShkadov(1024, dev, "f32", None, L0=699.2, n_jets=10)
+    env.reset()
+    a10 = torch.as_tensor(rng.uniform(-1, 1, (1024, 10)), dtype=env.tdtype, device=dev)
+    ms = timed(env, lambda: env.step(a10), 30, warm=5)
+    line("shkadov-v0 N=4096 10 jets B=1024 float32 (configs[2])", env, ms, 32.0 * env.nx * env.ndt_act * 1024)
+    env.close()
+    # sloshing (reference default grid) B=1024: 32 B per cell per timestep
+    env = V.VecSloshing(1024, dev, "f32", packaged_init("sloshing"))
+    env.reset()
+    ms = timed(env, lambda: env.step(a1), 50, warm=5)
+    line("sloshing-v0 N=200 B=1024 float32", env, ms, 32.0 * (env.nx + 2) * env.ndt_act * 1024)
+    env.close()
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="replicas per GPU")
-    ap.add_argument("--dtype", default="f32")
-    ap.add_argument("--variant", type=int, default=-1, help="-1 = best available, 0 = generic kernel")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--zero-actions", action="store_true",
-                    help="diagnostic: uncontrolled steady flow (1 Jacobi sweep per timestep) -> non-Poisson cost")
-    args = ap.parse_args()
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # not launched by torch.distributed.run: start one fresh process per GPU BEFORE anything here touches
+        # the GPU (this process never does), and leave rank 0 to print the line
+        sys.exit(launch_children(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N"
-                         % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
-    from beacon_amd import vec as V
     from beacon_amd.dist import ShardedVecEnv
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+
+    if args.stub:
+        dev = "cpu"
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.stub:
+            dist.init_process_group(args.backend)
+        else:
+            dist.init_process_group(args.backend, device_id=torch.device(dev))
 
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("--scaling strong: global batch %d is not divisible by %d GPUs" % (args.batch, world))
+        B = args.batch // world
+    else:
+        B = args.batch
+    Bg = B * world
+    K, W = args.steps, args.warmup
     L, H = 2.56, 1.28
-    z = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))
-    init = z["fields"]
-    B, K, W = args.batch, args.steps, args.warmup
-    env = V.VecRayleigh(B, dev, args.dtype, init, L=L, H=H)
-    if args.variant >= 0:
-        env.set_variant(args.variant)
+    init = None
+    if args.stub:
+        env = StubEnv(B)
+    else:
+        from beacon_amd import vec as V
+        init = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))["fields"]
+        env = V.VecRayleigh(B, dev, args.dtype, init, L=L, H=H)
+        if args.variant >= 0:
+            env.set_variant(args.variant)
+        if args.sched >= 0:
+            env.set_sched(args.sched)
     senv = ShardedVecEnv(env)
-    acts_np = np.random.default_rng(1234 + rank).uniform(-1.0, 1.0, (W + K, B, env.n_sgts))
+    # one global action stream, every rank takes the slice of its replicas (weak: a longer stream)
+    acts_g = np.random.default_rng(1234).uniform(-1.0, 1.0, (W + K, Bg, env.n_sgts))
     if args.zero_actions:
-        acts_np[:] = 0.0
+        acts_g[:] = 0.0
+    acts_np = acts_g[:, senv.lo:senv.hi]
     acts = torch.as_tensor(acts_np, dtype=env.tdtype, device=dev)
     senv.reset()
-    sweeps_all = []
 
     def sync():
-        torch.cuda.synchronize()
+        if not args.stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.stub:
+            torch.cuda.synchronize()
 
     for k in range(W):
         senv.step(acts[k], scattered=True)
     sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    state_after_warmup = None
+    if rank == 0 and not args.stub and not args.no_cpu and world == 1:
+        state_after_warmup = env.get_state()[:min(os.cpu_count() or 1, B)].cpu().numpy().astype(np.float64)
+        sync()
+    use_ev = not args.stub
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_ev else []
+    sweeps_all, cyc_all = [], []
     t0 = time.perf_counter()
     for k in range(K):
-        ev[k][0].record()
-        env.step(acts[W + k])                       # the one HIP launch of this step
-        ev[k][1].record()
+        if use_ev:
+            ev[k][0].record()
+        env.step(acts[W + k])                       # the one HIP launch of this step (torch's current stream)
+        if use_ev:
+            ev[k][1].record()
         sweeps_all.append(env.sweeps.clone())       # tiny device copy, for the roofline accounting
-        if world > 1:                                # trainer-facing gather, inside the timed region
-            senv.sh.gather("obs", env.obs), senv.sh.gather("rwd", env.rwd)
-            senv.sh.gather("done", env.done), senv.sh.gather("trunc", env.trunc)
+        if world > 1:                               # trainer-facing gather (one collective), inside the timed region
+            senv._gather()
     sync()
     elapsed = time.perf_counter() - t0
     env.check_status()
+    cyc = env.get_counters().astype(np.float64)     # of the last step
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
-    kern_ms = [s.elapsed_time(e) for s, e in ev]
-    esz = 4 if args.dtype == "f32" else 8
-    alg = [algorithmic_bytes(env.nx, env.ny, s.cpu().numpy(), esz) for s in sweeps_all]
-    mean_sw = float(np.mean([float(s.float().mean()) for s in sweeps_all]))
     if rank == 0:
-        achieved = (sum(alg) / len(alg)) / (sum(kern_ms) / len(kern_ms) * 1e-3) / 1e9
+        kern_ms = [s.elapsed_time(e) for s, e in ev] if use_ev else [1e3 * elapsed / K] * K
+        esz = 4 if args.dtype == "f32" else 8
+        sw_np = [s.cpu().numpy() for s in sweeps_all]
+        alg = [algorithmic_bytes(env.nx, env.ny, s, esz) for s in sw_np]
+        mean_sw = float(np.mean([s.mean() for s in sw_np]))
+        launch_s = sum(kern_ms) / len(kern_ms) * 1e-3
+        achieved = (sum(alg) / len(alg)) / launch_s / 1e9
+        kname = env.kernel_name
+        cells = env.nx * env.ny
+        sweeps_per_launch = float(np.mean([s.sum() for s in sw_np]))
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname, "avg_launch_ms": launch_s * 1e3,
+                "algorithmic_bytes_per_launch": sum(alg) / len(alg),
+                "note": "effective GB/s = SURVEY 8d algorithmic bytes / launch time (HIP events on the launch "
+                        "stream); a replica's state stays in registers/LDS inside the launch, so frac > 1 says that "
+                        "HBM is not the binding resource: see `binding` (VALU issue) and `hbm_measured`"}
+        tr = committed_profile(kname, "hbm_bytes_per_dispatch")
+        if tr:
+            roof["traffic"] = tr["value"]
+            roof["hbm_measured"] = {"bytes_per_launch": tr["value"], "GB/s": tr["value"] / launch_s / 1e9,
+                                    "frac_of_peak": tr["value"] / launch_s / 1e9 / HBM_PEAK_GBS,
+                                    "source": "profiles/" + tr["source"]}
+        # Poisson phase alone (what north_star's ">= 50 % on the Poisson sweep" refers to): share of the replicas'
+        # shader cycles spent inside the Jacobi loop (in-kernel s_memtime, last step) x launch time
+        if cyc[:, 1].sum() > 0:
+            share = float(cyc[:, 0].sum() / cyc[:, 1].sum())
+            pb = 12.0 / 4 * esz * cells * float(sw_np[-1].sum())
+            roof["poisson"] = {"time_share": share, "achieved": pb / (share * kern_ms[-1] * 1e-3) / 1e9, "unit": "GB/s",
+                               "frac": pb / (share * kern_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "cycles_per_replica_sweep": float(cyc[:, 0].sum() / max(1.0, float(sw_np[-1].sum())))}
+        # binding resource: VALU issue.  Instructions from the committed SQ_INSTS_VALU pass, scaled to this run's
+        # sweeps; the minimum-instruction variant counts 7 VALU instructions per cell and sweep.
+        vi = committed_profile(kname, "SQ_INSTS_VALU")
+        binding = {"bound": "valu_issue", "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instructions/s",
+                   "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+                   "min_instr_achieved": MIN_VALU_PER_CELL_SWEEP * cells / 64.0 * sweeps_per_launch / launch_s}
+        binding["min_instr_frac"] = binding["min_instr_achieved"] / VALU_ISSUE_PEAK
+        if vi and vi.get("sweeps_per_dispatch"):
+            insts = vi["value"] * sweeps_per_launch / vi["sweeps_per_dispatch"]
+            binding.update({"achieved": insts / launch_s, "frac": insts / launch_s / VALU_ISSUE_PEAK,
+                            "source": "profiles/" + vi["source"]})
+        roof["binding"] = binding
+        metric = "aggregate env steps/sec, rayleigh-v0 batch=512%s 128x64" % ("/GPU" if args.scaling == "weak" else " global")
         out = {
-            "metric": "aggregate env steps/sec, rayleigh-v0 batch=512/GPU 128x64",
-            "value": world * B * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "metric": metric,
+            "value": Bg * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": args.dtype, "data": "stub" if args.stub else "synthetic",
             "config": {"workload": "rayleigh-v0 (BASELINE configs[3]): L=2.56 H=1.28 -> 128x64 MAC grid, "
                                    "%d replicas per GPU, 200 timesteps per step, Jacobi to tol=1e-8" % B,
-                       "global_batch": world * B, "grid": [env.nx, env.ny], "ndt_act": env.ndt_act,
+                       "global_batch": Bg, "grid": [env.nx, env.ny], "ndt_act": env.ndt_act,
                        "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world,
-                       "kernel": env.kernel_name},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (measured_traffic(env.kernel_name) or {}).get("bytes_per_step"),
-                         "traffic_source": (measured_traffic(env.kernel_name) or {}).get("source"),
-                         "kernel": env.kernel_name, "avg_launch_ms": sum(kern_ms) / len(kern_ms),
-                         "algorithmic_bytes_per_launch": sum(alg) / len(alg),
-                         "note": "effective GB/s = SURVEY 8d algorithmic bytes / launch time; state stays "
-                                 "on-chip/L2 inside the launch, so this is not HBM traffic (see `traffic`); on chip "
-                                 "the kernel is VALU-issue bound: SQ_ACTIVE_INST_VALU = 40 % of wave cycles with "
-                                 "2 waves per SIMD (profiles/r01d_sq_counters.json)"},
+                       "kernel": kname},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(init, acts_np[W:], dict(L=L, H=H))
+        if world == 1 and not args.no_cpu and not args.stub:
+            out["cpu_baseline"] = cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H))
+        if world == 1 and not args.no_secondary and not args.stub:
+            env.close()
+            out["secondary"] = secondary_lines(dev)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

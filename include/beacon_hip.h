@@ -171,6 +171,17 @@ BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);
  * rayleigh 128x64 f32/f64, 50x50 f32/f64, 100x50 / 150x50 / 200x50 / 100x100 f32; mixing 100x100 f32.
  * Results of the two variants agree to rounding (float64: 1e-9).  Returns the variant actually selected. */
 BCN_API int bcn_set_variant(bcn_env_t h, int variant);
+/* Measurement aid (no reference counterpart): shader-clock cycles the last *_step spent per replica
+ * inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463) and in the whole replica (all chunks),
+ * uint64[B][2] on the host; zeros for kernels that do not count (generic 2D kernel, 1D envs). */
+BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
+/* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference
+ * counterpart: the reference steps one env per process, rayleigh.py:138-157).  mode: -1 = default
+ * (environment BCN_SCHED, else 2), 0 = one workgroup per replica in one launch, 1 = two launches with the
+ * replicas re-ordered longest-first, 2 = persistent workgroups drawing (chunk of q timesteps, replica)
+ * tickets; grid = persistent workgroups (0 = one per CU); q = timesteps per chunk (0 = kernel default);
+ * lpt_min_batch = smallest batch that mode 1 splits (0 = CUs + 1).  Results do not depend on the mode. */
+BCN_API int bcn_set_sched(bcn_env_t h, int mode, int grid, int q, int lpt_min_batch);
 /* name of the kernel the last *_step dispatched, e.g. "ns2d_fast_sched" (before the first step: the
  * variant's plain kernel); for profiles */
 BCN_API const char* bcn_kernel_name(bcn_env_t h);

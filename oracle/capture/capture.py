@@ -224,6 +224,29 @@ def job_rayleigh_128x64():
     save("rayleigh_128x64", **out)
 
 
+def job_rayleigh_128x64_step(k):
+    """One FULL reference step() (200 timesteps, ~93 Jacobi sweeps each) at the BASELINE grid from the bench's
+    developed initial state (tests/golden/rayleigh_128x64_init.npz) with the action vector bench.py gives replica k
+    at its first step: default_rng(1234).uniform(-1, 1, (steps, B, 10))[0, k].  Pins the float32 tolerance of the
+    timed dispatch against the reference itself (pure-Python loops here: ~10 minutes)."""
+    mod, d = load_ref("rayleigh")
+    s = mod.rayleigh(init=False, L=2.56, H=1.28)
+    s.reset_fields()
+    init = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"]
+    s.u[:], s.v[:], s.p[:], s.T[:] = init
+    act = np.random.default_rng(1234).uniform(-1.0, 1.0, (k + 1, s.n_sgts))[k]
+    rec = StageRecorder(mod, "T", 0)
+    t0 = time.time()
+    obs, rwd, done, trunc, _ = s.step(act.tolist())
+    rec.restore()
+    print("rayleigh_128x64_step%d mean itp %.1f  %.1fs" % (k, np.mean(rec.itp), time.time() - t0), flush=True)
+    out = dict(replica=k, action=act, obs=obs.copy(), rwd=rwd, a_norm=np.array(s.a),
+               itp=np.array(rec.itp, dtype=np.int64))
+    for f in "uvpT":
+        out[f] = getattr(s, f).copy()
+    save("rayleigh_128x64_step%d" % k, **out)
+
+
 def job_mixing(action):
     """mixing 100x100 from reset, one step() of 3 timesteps with `action`
     (first Poisson solve from rest takes ~2.5k sweeps: pins M3's stop logic)."""
@@ -470,6 +493,8 @@ JOBS = {
     "init_data": job_init_data,
     "rayleigh_default": job_rayleigh_default,
     "rayleigh_128x64": job_rayleigh_128x64,
+    "rayleigh_128x64_step0": lambda: job_rayleigh_128x64_step(0),
+    "rayleigh_128x64_step1": lambda: job_rayleigh_128x64_step(1),
     "mixing_a0": lambda: job_mixing(0),
     "mixing_a1": lambda: job_mixing(1),
     "mixing_a2": lambda: job_mixing(2),

@@ -26,6 +26,8 @@ def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "beacon_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        if os.environ.get("BEACON_NO_BUILD") == "1":   # profiled processes must not spawn compilers
+            raise RuntimeError("oracle/liboracle.so is missing or stale and BEACON_NO_BUILD=1")
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
     return so
 

@@ -1,34 +1,52 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 outputs of scripts/prof_bench.sh to one JSON summary (kept under profiles/)."""
+"""Reduce the rocprofv3 outputs of scripts/prof.sh to one JSON summary (kept under profiles/):
+kernel stats, HBM bytes per dispatch from the FETCH_SIZE / WRITE_SIZE passes, SQ counters per dispatch and
+the VALU-issue fraction (wave64 VALU instructions / (CUs x 4 SIMDs x clock / 2) / duration)."""
 import csv, glob, json, os, re, sys
+
+N_CU, CLK = 256, 2.4e9
 
 
 def kname(full):
-    m = re.search(r"(ns2d_\w+|\w+_step_k)(<[^>]*>)?", full)
+    m = re.search(r"(ns2d_\w+|\w+_step_k|\w+_kernel)(<[^>]*>)?", full)
     return (m.group(1) + (m.group(2) or "")) if m else None
 
+
 out = sys.argv[1]
-res = {"kernels": {}, "pmc": {}}
+res = {"command": sys.argv[2] if len(sys.argv) > 2 else "", "kernels": {}, "pmc": {}}
+# the profiled program's own JSON line(s), e.g. bench.py's (mean sweeps per timestep -> sweeps per dispatch)
+lines = []
+for f in sorted(glob.glob(os.path.join(out, "*_stdout.log"))):
+    for ln in open(f, errors="replace"):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                lines.append((os.path.basename(f), json.loads(ln)))
+            except Exception:
+                pass
+res["program_lines"] = {k: v for k, v in lines if k.startswith("trace")}
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = kname(r["Name"])
         if name:
             res["kernels"][name] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                     "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
-for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") != ctr:
-                continue
             name = kname(r["Kernel_Name"])
             if not name:
                 continue
-            a = acc.setdefault(name, [0, 0.0])
-            a[0] += 1
+            a = acc.setdefault((name, r["Counter_Name"]), [set(), 0.0])
+            a[0].add(r["Dispatch_Id"])
             a[1] += float(r["Counter_Value"])
-        for name, (n, v) in acc.items():
-            res["pmc"].setdefault(name, {})[ctr] = {"dispatches": n, "mean_per_dispatch_raw": v / n}
+        for (name, ctr), (ids, v) in acc.items():
+            c = res["pmc"].setdefault(name, {})
+            if ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                c[ctr] = {"dispatches": len(ids), "mean_per_dispatch_raw": v / len(ids)}
+            else:
+                c[ctr] = v / len(ids)
 # corrections (MI355X_MICROARCH.md, HBM): counters are in KiB; FETCH_SIZE reads half the bytes of a
 # wide coalesced read stream on gfx950 (doubled here as the guide prescribes); WRITE_SIZE is exact.
 for name, c in res["pmc"].items():
@@ -37,4 +55,19 @@ for name, c in res["pmc"].items():
     if fe is not None and wr is not None:
         c["hbm_bytes_per_dispatch"] = (2.0 * fe + wr) * 1024.0
         c["note"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024"
+    wc = c.get("SQ_WAVE_CYCLES")
+    if wc:
+        c["fraction_of_wave_cycles"] = {k: round(c[k] / wc, 4) for k in
+                                        ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA",
+                                         "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c}
+    k = res["kernels"].get(name)
+    if k and c.get("SQ_INSTS_VALU"):
+        c["valu_issue_frac"] = c["SQ_INSTS_VALU"] / (k["avg_ms"] * 1e-3) / (N_CU * 4 * CLK / 2.0)
+        c["valu_issue_note"] = "SQ_INSTS_VALU / avg kernel duration (trace pass) / (256 CUs x 4 SIMDs x 2.4 GHz / 2)"
+    for _, ln in lines:   # bench.py: Jacobi sweeps one dispatch executes
+        cfg = ln.get("config", {})
+        if "mean_jacobi_sweeps_per_timestep" in cfg and name.startswith(str(cfg.get("kernel", "?"))):
+            per_gpu = cfg["global_batch"] // max(1, ln.get("n_gpus", 1))
+            c["sweeps_per_dispatch"] = cfg["mean_jacobi_sweeps_per_timestep"] * cfg["ndt_act"] * per_gpu
+            break
 print(json.dumps(res, indent=1))

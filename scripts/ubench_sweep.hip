@@ -185,6 +185,66 @@ __global__ __launch_bounds__(512) void sweepC(float* out, const float* in, int n
   out[blockIdx.x * 512 + tid] = r;
 }
 
+
+// ---- D: mapping A re-ordered so that nothing dependent sits in front of the barrier --------------------------
+// (1) the two strip-edge cells are computed in the MIDDLE of the sweep (after H interior cells have covered the
+//     latency of the halo reads) and their LDS stores are covered by the remaining interior cells;
+// (2) LAG = 1: the wave reduction of a sweep's residual partial is done DURING the next sweep, one DPP step after
+//     each of its first interior cells, and published before that sweep's barrier: the convergence decision about
+//     sweep k is taken early in sweep k+2 (phi rotates through three arrays so that phi_k is still intact then);
+//     LAG = 0: reduction at the end of the sweep as in A (two arrays).
+template <int LAG, int H>
+__global__ __launch_bounds__(512) void sweepD(float* out, const float* in, int nsweep, float cx) {
+  constexpr int R = 16, NW = 8;
+  __shared__ float ex[2][NW][2][64];
+  __shared__ __attribute__((aligned(16))) float errp[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float A[R], B[R], C[R], nb[R];
+  for (int k = 0; k < R; k++) { A[k] = 0; B[k] = 0; C[k] = 0; nb[k] = in[((blockIdx.x * 1024 + tid) * 16 + k) % (256 * 512 * 16)]; }
+  const float cB = (lane == 0 || lane == 63) ? cx : 0.f, wl = 1.f + (lane == 0) + (lane == 63);
+  const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
+  float hWr = 0, hEr = 0, e8[NW], errsum = 0, ppart = 0;
+  for (int q = 0; q < NW; q++) e8[q] = 0;
+  int xb = 0;
+#define CELLD(c, e, wv, nbk) (cx * add2dpp((e) + (wv), c) + (cB * (c) + (nbk)))
+#define INTERIOR(S, D, k) { float ph = CELLD(S[k], S[k + 1], S[k - 1], nb[k]); float d = ph - S[k]; acc += d * d; D[k] = ph; }
+#define SWEEPD(S, D)                                                                     \
+  {                                                                                      \
+    float acc = 0, red = ppart;                                                          \
+    _Pragma("unroll") for (int k = 1; k <= H; k++) {                                     \
+      INTERIOR(S, D, k)                                                                  \
+      if (LAG) {                                                                         \
+        if (k == 1) red += dppf<0x111, 0xf>(red);                                        \
+        if (k == 2) red += dppf<0x112, 0xf>(red);                                        \
+        if (k == 3) red += dppf<0x114, 0xf>(red);                                        \
+        if (k == 4) red += dppf<0x118, 0xf>(red);                                        \
+        if (k == 5) red += dppf<0x142, 0xa>(red);                                        \
+        if (k == 6) red += dppf<0x143, 0xc>(red);                                        \
+      }                                                                                  \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    const float hW = (w > 0) ? hWr : S[0], hE = (w < NW - 1) ? hEr : S[R - 1];           \
+    const float p0 = CELLD(S[0], S[1], hW, nb[0]), pl = CELLD(S[R - 1], hE, S[R - 2], nb[R - 1]); \
+    const float d0 = p0 - S[0], dl = pl - S[R - 1]; D[0] = p0; D[R - 1] = pl;            \
+    ex[xb][w][0][lane] = p0; ex[xb][w][1][lane] = pl;                                    \
+    if (LAG) { if (lane == 63) errp[xb][w] = red; }                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    _Pragma("unroll") for (int k = H + 1; k < R - 1; k++) INTERIOR(S, D, k)              \
+    { _Pragma("unroll") for (int st = 1; st < NW; st *= 2) _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) e8[q] += e8[q + st]; \
+      errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e8[0]), 0)); } \
+    ppart = wl * acc + wl * (d0 * d0) + wl * (dl * dl);                                  \
+    if (!LAG) { const float tot = wave_sum63(ppart); if (lane == 63) errp[xb][w] = tot; } \
+    __syncthreads();                                                                     \
+    _Pragma("unroll") for (int q = 0; q < NW; q++) e8[q] = errp[xb][q];                  \
+    hWr = ex[xb][wm][1][lane]; hEr = ex[xb][wp][0][lane]; xb ^= 1;                       \
+  }
+  if (LAG) { for (int it = 0; it < nsweep; it += 3) { SWEEPD(A, B) SWEEPD(B, C) SWEEPD(C, A) } }
+  else { for (int it = 0; it < nsweep; it += 2) { SWEEPD(A, B) SWEEPD(B, A) } }
+  float r = errsum;
+  for (int k = 0; k < R; k++) r += A[k] + B[k] + C[k];
+  out[(blockIdx.x * 1024 + tid) % (256 * 512)] = r;
+}
+
 int main() {
   const int nwg = 256, nsweep = 4000;
   float *in, *out;
@@ -197,13 +257,14 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   int clk = 0;
   hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-  const char* names[14] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
+  const char* names[20] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
                           "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell", "C  A0 with two sweeps per barrier (depth-2 halos)",
                           "A0 with 16 waves x 8 columns", "A0 with 4 waves x 32 columns", "A0 with 12 waves x 11 columns (132 columns: x 0.97)",
                           "A0 with 13 waves x 10 columns (130 columns)", "A0 with 10 waves x 13 columns (130 columns)",
-                          "A4 two residual accumulators", "A5 no sched_barrier", "A6 no interior residual (floor, wrong)"};
+                          "A4 two residual accumulators", "A5 no sched_barrier", "A6 no interior residual (floor, wrong)",
+                          "D  edges mid-sweep (H=6), reduction at the end", "D  edges mid-sweep (H=6), LAGGED reduction, 3 arrays", "D  edges mid-sweep (H=8), LAGGED reduction", "D  edges mid-sweep (H=4), reduction at the end", "D edges mid-sweep (H=10), LAGGED", "D edges at end (H=14), LAGGED"};
   for (int rep = 0; rep < 2; rep++)
-    for (int v = 0; v < 14; v++) {
+    for (int v = 0; v < 20; v++) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(sweepA<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 1) hipLaunchKernelGGL(sweepA<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
@@ -214,6 +275,12 @@ int main() {
       if (v == 11) hipLaunchKernelGGL(sweepA<4>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 12) hipLaunchKernelGGL(sweepA<5>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 13) hipLaunchKernelGGL(sweepA<6>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 14) hipLaunchKernelGGL((sweepD<0, 6>), dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 15) hipLaunchKernelGGL((sweepD<1, 6>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
+      if (v == 16) hipLaunchKernelGGL((sweepD<1, 8>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
+      if (v == 17) hipLaunchKernelGGL((sweepD<0, 4>), dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 18) hipLaunchKernelGGL((sweepD<1, 10>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
+      if (v == 19) hipLaunchKernelGGL((sweepD<1, 14>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
       if (v == 6) hipLaunchKernelGGL((sweepA<0, 8, 16>), dim3(nwg), dim3(1024), 0, 0, out, in, nsweep, 0.25f);
       if (v == 7) hipLaunchKernelGGL((sweepA<0, 32, 4>), dim3(nwg), dim3(256), 0, 0, out, in, nsweep, 0.25f);
       if (v == 8) hipLaunchKernelGGL((sweepA<0, 11, 12>), dim3(nwg), dim3(768), 0, 0, out, in, nsweep, 0.25f);

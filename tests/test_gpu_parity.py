@@ -332,6 +332,161 @@ def test_rayleigh_bench_workload_f32_vs_f64():
         e.close()
 
 
+# ---------------------------------------------------------------------------------------------
+# the dispatch bench.py times: BASELINE configs[3] exactly as bench.py builds it
+# ---------------------------------------------------------------------------------------------
+def _bench_workload(B, nsteps, dtype):
+    """bench.py's inputs: developed 128x64 state, default_rng(1234).uniform(-1, 1, (steps, B, 10))."""
+    init = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"]
+    acts = np.random.default_rng(1234).uniform(-1.0, 1.0, (nsteps, B, 10))
+    env = V.VecRayleigh(B, DEV, dtype, init, L=2.56, H=1.28)
+    env.reset()
+    return env, init, acts
+
+
+def _oracle_batch_step(init, acts, nrep, L=2.56, H=1.28):
+    """One full action step of replicas 0..nrep-1 on the float64 C oracle (OpenMP over envs)."""
+    import ctypes as C
+    e = O.rayleigh(init=False, L=L, H=H)
+    n = (e.cfg.nx + 2) * (e.cfg.ny + 2)
+    st = np.zeros((nrep, 8, n))
+    st[:, :4] = init.reshape(1, 4, n)
+    e0 = O.rayleigh(init_fields=init, L=L, H=H)
+    obs = np.tile(e0.reset()[0], (nrep, 1))          # observation history after reset(): [0, 0, 0, reset sample]
+    rwd = np.zeros(nrep)
+    sw = np.zeros(nrep, dtype=np.int64)
+    a = np.ascontiguousarray(acts[:nrep].astype(np.float64))
+    O.lib().orc_ns2d_step_batch(C.byref(e.cfg), nrep, O.dp(st.reshape(-1)), O.dp(a.reshape(-1)), a.shape[1],
+                                O.dp(obs.reshape(-1)), O.dp(rwd), sw.ctypes.data_as(C.POINTER(C.c_int64)),
+                                min(nrep, os.cpu_count() or 1))
+    return st[:, :4].reshape(nrep, 4, e.cfg.nx + 2, e.cfg.ny + 2), obs, rwd, sw
+
+
+@pytest.mark.parametrize("dtype,ftol,swtol", [("f32", 5e-5, 3), ("f64", F64_TOL, 1)])
+def test_rayleigh_bench_dispatch_vs_oracle_and_reference(dtype, ftol, swtol):
+    """The timed dispatch itself -- B=512, 128x64, 200 timesteps, default scheduler: `ns2d_fast_sched` -- against
+    (a) the float64 C oracle on replicas 0..7 over one FULL action step and (b) the reference's own full step for
+    replicas 0 and 1 (tests/golden/rayleigh_128x64_step{0,1}.npz, captured by oracle/capture/capture.py).
+    float32 tolerance, stated against the float64 reference: fields/obs 5e-5 absolute (|T| <= 1.25, |u|,|v| < 0.3;
+    measured 4e-6), p 50x that (200 accumulated phi), reward 1e-4, total sweeps of the step within 1 % and per
+    timestep within 3; float64: 1e-9 with equal sweep counts (+-1 at the threshold)."""
+    B, NREP = 512, 8
+    env, init, acts = _bench_workload(B, 1, dtype)
+    obs, rwd, done, trunc, _ = env.step(acts[0])
+    env.check_status()
+    assert env.kernel_name == "ns2d_fast_sched"
+    st = dev2ref(env.get_state()[:NREP])
+    sw = env.sweeps.cpu().numpy()[:NREP]
+    o = obs.cpu().numpy().astype(np.float64)[:NREP]
+    r = rwd.cpu().numpy().astype(np.float64)[:NREP]
+    ost, oobs, orwd, osw = _oracle_batch_step(init, acts[0], NREP)
+    for b in range(NREP):
+        for i, F in enumerate("uvpT"):
+            assert maxdiff(st[b][i], ost[b][i]) <= ftol * (50 if F == "p" else 1), (b, F)
+        assert maxdiff(o[b], oobs[b]) <= ftol and abs(r[b] - orwd[b]) <= max(1e-8, 2 * ftol)
+        assert abs(int(sw[b].sum()) - int(osw[b])) <= max(swtol, 0.01 * osw[b] if dtype == "f32" else 0), (b, sw[b].sum(), osw[b])
+    for b in (0, 1):                      # the reference itself
+        g = golden("rayleigh_128x64_step%d" % b)
+        assert np.array_equal(g["action"], acts[0, b])
+        for i, F in enumerate("uvpT"):
+            assert maxdiff(st[b][i], g[F]) <= ftol * (50 if F == "p" else 1), (b, F)
+        # the capture steps from loaded fields without reset()'s get_obs: only the newest history slot is comparable
+        assert maxdiff(o[b][-96:], g["obs"][-96:]) <= ftol and abs(r[b] - float(g["rwd"])) <= max(1e-8, 2 * ftol)
+        assert np.max(np.abs(sw[b] - g["itp"])) <= swtol, (b, np.max(np.abs(sw[b] - g["itp"])))
+    env.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_rayleigh_bench_dispatch_scheduler_is_bit_exact(dtype):
+    """B=512 bench workload, two action steps: the ticketed chunk scheduler (mode 2, the timed dispatch) against
+    one workgroup per replica in one launch (mode 0) -- obs, rewards, sweep counts and fields bit for bit (p ghost
+    cells, rebuilt once per chunk from the change of their interior neighbour, to one rounding)."""
+    outs = []
+    for mode in (2, 0):
+        env, init, acts = _bench_workload(512, 2, dtype)
+        env.set_sched(mode)
+        for k in range(2):
+            obs, rwd, _, _, _ = env.step(acts[k])
+        env.check_status()
+        assert env.kernel_name == ("ns2d_fast_sched" if mode == 2 else "ns2d_fast_step")
+        outs.append((obs.clone(), rwd.clone(), env.sweeps.clone(), env.get_state().clone()))
+        env.close()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for f in (0, 1, 3):
+        assert torch.equal(a[3][:, f], b[3][:, f])
+    assert torch.equal(a[3][:, 2, 1:-1, 1:-1], b[3][:, 2, 1:-1, 1:-1])
+    assert float((a[3][:, 2] - b[3][:, 2]).abs().max()) < (1e-4 if dtype == "f32" else 1e-12)
+
+
+def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler():
+    """mixing-v0 at BASELINE configs[4]'s batch: B=512, 100x100, one full 250-timestep step from rest through
+    `ns2d_fast2_sched` (256 persistent workgroups): replicas 0..3 (actions 0..3) against the float64 C oracle
+    (float32 tolerance as test_mixing_from_rest_vs_golden: 2e-4, sweeps within 2 %), and the whole batch bit for
+    bit against the unscheduled launch."""
+    B = 512
+    a = (np.arange(B) % 4).astype(np.int64)
+    outs = []
+    for mode in (2, 0):
+        env = V.VecMixing(B, DEV, "f32")
+        env.set_sched(mode)
+        env.reset()
+        obs, rwd, _, _, _ = env.step(a)
+        env.check_status()
+        assert env.kernel_name == ("ns2d_fast2_sched" if mode == 2 else "ns2d_fast2_step")
+        outs.append((obs.clone(), rwd.clone(), env.sweeps.clone(), env.get_state().clone()))
+        env.close()
+    x, y = outs
+    assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+    for f in (0, 1, 3):
+        assert torch.equal(x[3][:, f], y[3][:, f])
+    assert torch.equal(x[3][:, 2, 1:-1, 1:-1], y[3][:, 2, 1:-1, 1:-1])
+    st = dev2ref(x[3][:4])
+    sw = x[2].cpu().numpy()
+    for b in range(4):
+        o = O.mixing()
+        o.reset()
+        ob, rw, _, _, _ = o.step(int(a[b]))
+        for i, F in enumerate("uvpC"):
+            assert maxdiff(st[b][i], o.st[i]) <= 2e-4 * (50 if F == "p" else 1), (b, F)
+        assert maxdiff(x[0][b].cpu().numpy(), ob) <= 2e-4 and abs(float(x[1][b]) - rw) <= 1e-5
+        assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(3, 0.02 * o.itp)), b
+        assert torch.equal(x[0][b], x[0][b + 4])          # same action -> same replica, whatever CU ran it
+
+
+def test_rayleigh_bench_episode_is_deterministic_with_staggered_resets():
+    """(was scripts/soak.py + scripts/stress.py) 24 action steps of the bench configuration, B=512, episode
+    counters staggered so that replicas end their episode at different steps and are auto-reset one by one through
+    masks and the ticket scheduler; run twice: bit-identical, every status word 0, reset replicas restart from the
+    developed state."""
+    init = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"]
+    B, N = 512, 24
+    acts = torch.as_tensor(np.random.default_rng(11).uniform(-1, 1, (8, B, 10)), dtype=torch.float32, device=DEV)
+    outs = []
+    for run in range(2):
+        env = V.VecRayleigh(B, DEV, "f32", init, L=2.56, H=1.28)
+        obs0, _ = env.reset()
+        obs0 = obs0.clone()
+        env.set_stp((np.arange(B) * 7) % env.n_act)            # staggered episode ends
+        resets, rw = 0, []
+        for k in range(N):
+            obs, rwd, done, trunc, _ = env.step(acts[k % 8])
+            rw.append(rwd.clone())
+            n = int(done.sum().item())
+            if n:
+                d = done.clone().bool()
+                env.reset_done()
+                resets += n
+                assert torch.equal(env.obs[d], obs0[d])        # back to the reset observation
+        st = env.check_status()
+        assert (st == 0).all() and resets > 0
+        assert env.kernel_name == "ns2d_fast_sched"
+        outs.append((env.get_state().clone(), torch.stack(rw), env.obs.clone(), resets))
+        env.close()
+    assert outs[0][3] == outs[1][3]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 @pytest.mark.parametrize("L,nx", [(2.0, 100), (3.0, 150), (4.0, 200)])
 def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
     """Register-resident instantiations for the reference's other natural aspect ratios (nx = 50 L, ny = 50):

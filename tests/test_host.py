@@ -3,6 +3,7 @@ declares, derived env parameters match the reference constructors (SURVEY.md 8a.
 host-only lorenz env matches the golden episodes, and the replica-sharding collectives work
 across two processes (gloo)."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -123,7 +124,8 @@ def test_shard_bounds():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
-from beacon_amd.dist import ReplicaSharder, shard_bounds
+from beacon_amd.dist import ReplicaSharder, ShardedVecEnv, shard_bounds
+from beacon_amd.vec import out_layout, unpack_outputs
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 B = 6
@@ -133,16 +135,47 @@ lo, hi = shard_bounds(sh.global_batch, world, rank)
 full = torch.arange(sh.global_batch * 3, dtype=torch.float32).reshape(sh.global_batch, 3)
 mine = sh.scatter_actions(full if rank == 0 else None, torch.empty((B, 3), dtype=torch.float32))
 assert torch.equal(mine, full[lo:hi]), (rank, mine)
-for step in range(3):                                   # receive buffers are reused across steps
-    obs = (mine * 2 + step).contiguous()
-    rwd = mine.sum(1)
-    done = (torch.arange(B) + rank).to(torch.uint8)
-    g_obs, g_rwd, g_done = sh.gather("obs", obs), sh.gather("rwd", rwd), sh.gather("done", done)
+# packed per-step outputs: ONE collective per step, receive buffer reused across steps
+buf = torch.zeros((out_layout(B, 3, 4)["bytes"],), dtype=torch.uint8)
+obs, rwd, status, done, trunc = unpack_outputs(buf, B, 3, torch.float32)
+for step in range(3):
+    obs[:] = mine * 2 + step
+    rwd[:] = mine.sum(1)
+    status[:] = rank
+    done[:] = (torch.arange(B) + rank).to(torch.uint8)
+    trunc[:] = step
+    g = sh.gather_outputs(buf, 3, torch.float32)
     if rank == 0:
+        g_obs, g_rwd, g_status, g_done, g_trunc = g
         assert torch.equal(g_obs, full * 2 + step) and torch.equal(g_rwd, full.sum(1))
+        assert g_status.tolist() == [0] * B + [1] * B and g_trunc.tolist() == [step] * (2 * B)
         assert g_done.shape == (sh.global_batch,) and g_done[B:].tolist() == [(i + 1) %% 256 for i in range(B)]
     else:
-        assert g_obs is None and g_rwd is None
+        assert g is None
+
+
+class Env:                                               # CPU stand-in with the VecEnv surface
+    action_is_int, n_actions, batch, obs_dim, tdtype, device = False, 3, B, 3, torch.float32, torch.device("cpu")
+    def __init__(self):
+        self.out_buf = torch.zeros((out_layout(B, 3, 4)["bytes"],), dtype=torch.uint8)
+        self.obs, self.rwd, self.status, self.done, self.trunc = unpack_outputs(self.out_buf, B, 3, torch.float32)
+        self.gen = torch.Generator()
+    def reset(self):
+        self.obs.fill_(-1.0); return self.obs, None
+    def step(self, a, noise=None):
+        self.obs[:] = a + 1; self.rwd[:] = a.sum(1); self.done.fill_(1)
+        return self.obs, self.rwd, self.done, self.trunc, None
+
+
+senv = ShardedVecEnv(Env(), seed=5)
+assert senv.env.gen.initial_seed() == 5 + lo           # noise streams differ per rank
+o, _ = senv.reset()
+assert (o is None) == (rank != 0) and (rank != 0 or o.shape == (2 * B, 3))
+o, r, d, t, _ = senv.step(full if rank == 0 else None)
+if rank == 0:
+    assert torch.equal(o, full + 1) and torch.equal(r, full.sum(1)) and d.tolist() == [1] * (2 * B)
+else:
+    assert o is None
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -159,6 +192,24 @@ def test_replica_sharding_collectives_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def test_bench_self_launch_and_scalings_on_cpu_stub():
+    """`python bench.py --gpus 2` with no launcher: the parent starts one process per rank, rank 0 prints ONE JSON
+    line; weak scaling doubles the global batch, strong scaling shards the batch of 512.  Run with the CPU stand-in
+    env over gloo (the line is marked data=stub: launcher / sharding / gather plumbing only)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for scaling, per_gpu, glob in (("weak", 16, 32), ("strong", 8, 16)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                            "--batch", "16", "--scaling", scaling, "--stub", "--backend", "gloo"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["data"] == "stub" and d["steps"] == 3
+        assert d["config"]["global_batch"] == glob and ("%d replicas per GPU" % per_gpu) in d["config"]["workload"]
+        assert abs(d["value"] - glob * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
 
 
 def test_vortex_host_env_matches_reference_episodes():

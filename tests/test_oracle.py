@@ -258,3 +258,38 @@ def test_poisson_manufactured_known_answer():
            (ph[1:-1, 2:] - 2 * ph[1:-1, 1:-1] + ph[1:-1, :-2]) / cfg.dy ** 2)
     b = ((us[2:, 1:-1] - us[1:-1, 1:-1]) / cfg.dx) / cfg.dt
     assert np.abs(lap - b).max() < 1e-5 * np.abs(b).max()
+
+
+def test_numpy_port_is_bit_identical_to_the_reference():
+    """oracle/numpy_port.py (the vectorised-NumPy CPU leg of bench.py): two full action steps at 50x50 reproduce the
+    reference's fields, conditioned actions and all 400 Jacobi sweep counts bit for bit."""
+    from oracle import numpy_port as NP
+    g = golden("rayleigh_default")
+    e = NP.Rayleigh(init_fields=np.stack([g["u_init"], g["v_init"], g["p_init"], g["T_init"]]))
+    for k in range(2):
+        a = e.solve(g["actions"][k])
+        assert np.array_equal(a, g["step%d_a_norm" % k])
+        assert np.array_equal(np.array(e.itp), g["itp"][k])
+        for F in "uvpT":
+            assert np.array_equal(getattr(e, F), g["step%d_%s" % (k, F)]), (k, F)
+
+
+def test_oracle_full_step_128x64_matches_the_reference():
+    """BASELINE grid, bench.py's developed initial state and its first action vectors of replicas 0 and 1: one FULL
+    reference step() each (200 timesteps, 99 / 62 Jacobi sweeps per timestep), captured by
+    oracle/capture/capture.py rayleigh_128x64_step{0,1}.  The C oracle reproduces fields and every sweep count
+    bit for bit (reward: a BLAS-free reduction, 1e-13)."""
+    import os
+    from conftest import GOLD
+    init = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"]
+    for k in (0, 1):
+        g = golden("rayleigh_128x64_step%d" % k)
+        e = O.rayleigh(init=False, L=2.56, H=1.28)
+        e.reset_fields()
+        e.st[:4] = init
+        obs, rwd, done, trunc, _ = e.step(g["action"].tolist())
+        assert np.array_equal(e.itp, g["itp"])
+        for i, F in enumerate("uvpT"):
+            assert np.array_equal(e.st[i], g[F]), (k, F)
+        assert np.array_equal(obs, g["obs"]) and abs(rwd - float(g["rwd"])) <= 1e-13
+        assert np.array_equal(np.array(e.a), g["a_norm"])
