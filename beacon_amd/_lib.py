@@ -12,7 +12,7 @@ c_u8p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
 
 F32, F64 = 0, 1
-ST_OK, ST_ITMAX, ST_BLOWUP = 0, 1, 2
+ST_OK, ST_ITMAX, ST_BLOWUP, ST_PLAN = 0, 1, 2, 4
 
 
 class RayleighCfg(C.Structure):
@@ -86,6 +86,7 @@ SIGNATURES = {
     "bcn_set_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_variant": (C.c_int, [vp, C.c_int]),
     "bcn_get_counters": (C.c_int, [vp, C.POINTER(C.c_uint64), vp]),
+    "bcn_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "bcn_set_sched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bcn_kernel_name": (C.c_char_p, [vp]),
     "bcn_destroy": (C.c_int, [vp]),

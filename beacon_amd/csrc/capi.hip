@@ -87,6 +87,8 @@ struct NS2DEnv : bcn_env_s {
       a.fscr = static_cast<real*>(fscrbuf.p);
     }
     variant = fast_ok ? 1 : 0;
+    a.conv_plan = sizeof(real) == 4 ? 2 : 1;   // ns2d_fast.hip: float64 keeps the proven plan (exact stop sweep)
+    if (const char* e = getenv("BCN_CONV_PLAN")) a.conv_plan = atoi(e);
     return BCN_OK;
   }
   ~NS2DEnv() override {
@@ -118,6 +120,11 @@ struct NS2DEnv : bcn_env_s {
   int set_sched(int mode, int grid, int q, int lpt_min_batch) override {
     a.sched_mode = mode; a.sched_grid = grid; a.sched_q_user = q; a.lpt_min_batch = lpt_min_batch;
     return BCN_OK;
+  }
+  int set_option(const char* name, int value) override {
+    if (!strcmp(name, "conv_plan") && value >= 0 && value <= 2) { a.conv_plan = value; return BCN_OK; }
+    if (!strcmp(name, "verify_conv")) { a.verify_conv = value ? 1 : 0; return BCN_OK; }
+    return bcn_env_s::set_option(name, value);
   }
   int get_counters(uint64_t* host, hipStream_t s) override {
     BCN_HIP(hipMemcpyAsync(host, a.cyc, (size_t)batch * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -541,6 +548,10 @@ int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream) {
   if (!h || !buf_host) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
   DeviceGuard g(h->device);
   return h->get_counters(buf_host, static_cast<hipStream_t>(stream));
+}
+int bcn_set_option(bcn_env_t h, const char* name, int value) {
+  if (!h || !name) { bcn_set_error("null handle/name"); return BCN_ERR_ARG; }
+  return h->set_option(name, value);
 }
 int bcn_set_sched(bcn_env_t h, int mode, int grid, int q, int lpt_min_batch) {
   if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }

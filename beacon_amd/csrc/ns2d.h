@@ -51,6 +51,9 @@ struct NS2DArgs {
   unsigned long long* cyc;  // [B][2] shader-clock cycles of the last step: inside the Jacobi loop / whole replica (bcn_get_counters)
   size_t sched_bytes;       // bytes of sched_ctl + cyc: zeroed by one memset in front of every step launch
   int sched_q;              // timesteps per chunk
+  int conv_plan = 1;        // which Jacobi sweeps evaluate the residual: 0 all, 1 proven skips only, 2 + extrapolated (ns2d_fast.hip)
+  int verify_conv = 0;      // 1: evaluate the Jacobi residual after every sweep and flag BCN_ST_PLAN if the evaluation plan
+                            //    of the register-resident kernels would have skipped a sweep that passes the test (BCN_VERIFY_CONV=1)
   int sched_mode = -1;      // per-handle overrides of the BCN_SCHED* defaults (bcn_set_sched): -1 / 0 = default
   int sched_grid = 0, sched_q_user = 0, lpt_min_batch = 0;
   const char** launched;    // host side: receives the name of the kernel the launcher dispatched (may be NULL)

@@ -43,13 +43,6 @@
 #define BCN_R128D 16   // columns per lane of the float64 128x64 kernel
 #endif
 
-#ifndef BCN_ERRB
-#define BCN_ERRB 1   // error norm across the workgroup: wave DPP reduction -> NW partials in LDS, then
-                     // 1: every lane reads them by broadcast and adds them (1 238 cycles per sweep at 128x64);
-                     // 0: DPP row reduction of one partial per lane (1 328).  Tried and dropped: no reduction in
-                     // front of the barrier, every lane publishes its partial and every wave adds the NW rows
-                     // lane-wise afterwards (1 439: 16 KB of LDS reads per sweep).
-#endif
 
 namespace {
 
@@ -69,11 +62,11 @@ struct FastGeom {
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY + 16;  // +16: lanes >= NY read (never write) past the array
   static constexpr int PD = GF ? BCN_PDG : 4;   // transport prefetch depth (diagonals); deeper for global fields
-  // LDS map (elements): [ exchange 2*NW*3*64 | errp 32 | sact 64 | red 32 | .. FRONT ) U V T [ BACK )
+  // LDS map (elements): [ exchange 2*NW*2*64 | errp 64 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
   static constexpr int EXCH = 2 * NW * 2 * 64;              // [2 buffers][NW][west edge | east edge][64]
-  static constexpr int MISC = EXCH + 128 + 16;              // + 16: scheduler words (ns2d_fast_sched)
+  static constexpr int MISC = EXCH + 160 + 16;              // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + PD + 1) * SY;
   static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
@@ -157,8 +150,8 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
   using G = FastGeom<NX, NY, R, GF>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
   real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
-  real* errp = exch + G::EXCH;                 // [2][16]
-  real* sact = errp + 32;                      // [64]
+  real* errp = exch + G::EXCH;                 // [2][2][16]: reference norm / unweighted norm partials
+  real* sact = errp + 64;                      // [64]
   real* red = sact + 64;                       // [32]
   real* gscr = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride + G::FRONTG : nullptr;
   real* Ul = GF == 1 ? gscr : GF == 2 ? exch + G::MISCA : exch + G::FRONT;
@@ -184,7 +177,7 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     Tl[ii * SY + jj] = gS[c];
   }
   for (int c = SX * SY + tid; c < SZ; c += NT) { Ul[c] = 0; Vl[c] = 0; Tl[c] = 0; }
-  if (tid < 32) errp[tid] = 0;
+  if (tid < 64) errp[tid] = 0;
   real p[R];
 #pragma unroll
   for (int k = 0; k < R; k++) p[k] = active ? gp[j * SX + i0 + k] : real(0);
@@ -336,11 +329,25 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     BCN_PH(1)
     const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
     // ---- Jacobi sweeps (rayleigh.py:419-454): one barrier per sweep --------------------------
-    // phi ping-pongs between two register arrays (two sweeps per loop trip, no copies).  After
-    // the barrier the LDS reads (error partials, strip-edge halos) are issued first and the
-    // R-2 interior cells of the NEXT sweep are computed while they are in flight; only then is
-    // the convergence test of the finished sweep evaluated (if it passes, the partial next
-    // sweep is simply dropped) and the two edge cells are completed.
+    // phi ping-pongs between two register arrays (no copies).  Behind the barrier of a sweep the LDS reads of the
+    // strip-edge halos are issued first and the R-2 interior cells of the NEXT sweep are computed while they are in
+    // flight; the two edge cells follow and go to the exchange buffer at once.
+    //
+    // Which sweeps evaluate the residual.  The reference evaluates err_k = sum((phi_k - phi_{k-1})^2) over the whole
+    // array after EVERY sweep and stops at the first k with err_k <= tol (rayleigh.py:448-454).  A sweep is
+    // d_{k+1} = J d_k for the increments d_k, with J = (Adj + G) / 4 symmetric (Adj: neighbour matrix of the interior
+    // cells, G: diagonal count of mirrored ghost sides; a Dirichlet-zero ghost drops out), so the UNWEIGHTED interior
+    // norm a_k = |d_k|^2 = sum_i lambda_i^{2k} c_i^2 is log-convex in k: its per-sweep decay factor a_{k+1}/a_k never
+    // decreases.  Hence, from two evaluated sweeps kp < k, rho = (a_k / a_kp)^(1/(k-kp)) is a lower bound of every
+    // later factor, and err_{k+i} >= a_{k+i} >= a_k rho^i (the reference's norm counts the ghost copies on top of the
+    // interior: err = d'(I+G)d >= a).  While a_k rho^i > 1.02 tol the test cannot pass, and those sweeps run WITHOUT
+    // the residual (5 instead of 7 instructions per cell, no wave reduction, no partials through LDS).
+    // A.conv_plan: 0 = evaluate every sweep (the reference, literally); 1 = skip only what the bound above proves
+    // (exact stop sweep: the float64 default); 2 = additionally extrapolate the reference norm itself, whose decay
+    // factor is observed -- not proven: I+G does not commute with J -- never to decrease either (10 000 sweeps of
+    // oracle traces, scripts/plan_sim.py), stopping the skip 1 + 1/16 of its length early (the float32 default: the
+    // evaluations drop from ~28 % to ~10 % of the sweeps).  A.verify_conv evaluates every sweep anyway and raises
+    // BCN_ST_PLAN if a sweep the plan would have skipped passes the test (tests/test_gpu_parity.py).
     auto cell = [&](real c, real e, real wv, real nbk) -> real {
       const real q = cBy * c + nbk;                       // Neumann ghosts in y copy the cell itself
       real ph;
@@ -356,8 +363,8 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       return ph;
     };
     const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
-    real hW = 0, hE = 0;            // halos of the current source array
-    real eL = 0, hWr = 0, hEr = 0;  // LDS reads in flight
+    real hW = 0, hE = 0;            // halos of the array the last sweep read
+    real hWr = 0, hEr = 0;          // halos of the array the last sweep wrote (LDS reads issued behind its barrier)
     int itp = 0;
 #ifdef BCN_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -366,80 +373,126 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
 #pragma unroll
     for (int k = 0; k < R; k++) phA[k] = 0;
     bool finalB = false;
-#ifndef BCN_EXP
-#define BCN_EXP 0   // timing experiments only (wrong results): 1 fixed 100 sweeps, 2 no barrier, 4 no LDS exchange, 8 no reduction
+    int k_prev = -1;                // index of the planned evaluation before the last one, log2 of its two norms
+    float l2u_prev = 0, l2w_prev = 0;
+    int skip_left = 0;              // verify_conv: sweeps the plan would still skip
+#ifdef BCN_DBG_NCHK
+    int nchk = 0;
+#define BCN_NCHK_INC nchk++;
+#else
+#define BCN_NCHK_INC
 #endif
-    real eB[NW];
-#define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                        \
-    {                                                                                        \
-      real acc = 0;                                                                          \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                    \
-        const real ph = cell(SRC[k], SRC[k + 1], SRC[k - 1], nb[k]);                         \
-        const real d = ph - SRC[k];                                                          \
-        acc += d * d;                                                                        \
-        DST[k] = ph;                                                                         \
-      }                                                                                      \
-      const real pI = wl * acc;   /* the edge cells join below: short tail in front of the barrier */ \
-      /* keep the halo-dependent part behind the interior cells: hipcc otherwise sometimes hoists the  \
-         edge cells (and their s_waitcnt on the LDS reads) in front of them: +170 cycles per sweep */   \
+    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+    constexpr int JMAX = 256;
+    // all cells of one sweep; the two strip-edge cells come last (their halos were requested behind the previous
+    // barrier) and go to the exchange buffer at once, in front of whatever else the sweep still has to do
+#define BCN_CELLS(SRC, DST)                                                                  \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) DST[k] = cell(SRC[k], SRC[k + 1], SRC[k - 1], nb[k]); \
+      /* keep the halo-dependent part behind the interior cells: hipcc otherwise sometimes hoists the edge cells \
+         (and their s_waitcnt on the LDS reads) in front of them: +170 cycles per sweep */   \
       __builtin_amdgcn_sched_barrier(0);                                                     \
-      if (itp > 0) {                                                                         \
-        real err;                                                                            \
-        if (BCN_ERRB) {   /* every lane sums the NW partials it read by broadcast */         \
-          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                               \
-            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st]; \
-          err = read_lane(eB[0], 0);                                                         \
-        } else {                                                                             \
-          err = read_lane(row16_sum<real>(eL), 15);                                          \
-        }                                                                                    \
-        if (BCN_EXP & 1) err = (itp < 100) ? real(1e30) : err * real(0);                     \
-        hW = (w > 0) ? hWr : SRC[0];                                                         \
-        hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                \
-        if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }             \
-        if (!(err > A.tol)) { finalB = SRC_IS_B; break; }                                    \
-      }                                                                                      \
+      hW = (w > 0) ? hWr : SRC[0];                                                           \
+      hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                  \
       const real p0 = cell(SRC[0], SRC[1], hW, nb[0]);                                       \
       const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
-      const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
       DST[0] = p0;                                                                           \
       DST[R - 1] = pl;                                                                       \
-      const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
-      const real tot63 = (BCN_EXP & 8) ? part : wave_sum_lane63<real>(part);                 \
-      if (!(BCN_EXP & 4)) {                                                                  \
-        ex(xb, w, 0)[lane] = p0;                                                             \
-        ex(xb, w, 1)[lane] = pl;                                                             \
-        if (lane == 63) errp[xb * 16 + w] = tot63;                                           \
-      }                                                                                      \
-      if (!(BCN_EXP & 2)) __syncthreads();                                                   \
+      ex(xb, w, 0)[lane] = p0;                                                               \
+      ex(xb, w, 1)[lane] = pl;
+#define BCN_SWEEP_END                                                                        \
+      __syncthreads();                                                                       \
       itp++;                                                                                 \
-      if (!(BCN_EXP & 4)) {                                                                  \
-        if (BCN_ERRB) {                                                                      \
-          _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 16 + q];          \
-        } else {                                                                             \
-          eL = errp[xb * 16 + (lane & 15)];                                                  \
-        }                                                                                    \
-        hWr = ex(xb, wm, 1)[lane];                                                           \
-        hEr = ex(xb, wp, 0)[lane];                                                           \
-      } else {                                                                               \
-        eL = tot63; eB[0] = tot63; hWr = p0; hEr = pl;                                                    \
-      }                                                                                      \
+      hWr = ex(xb, wm, 1)[lane];                                                             \
+      hEr = ex(xb, wp, 0)[lane];                                                             \
+      xb ^= 1;
+    // a sweep that does not evaluate the residual
+#define BCN_FAST(SRC, DST) { BCN_CELLS(SRC, DST) BCN_SWEEP_END }
+    // a sweep that does (the same arithmetic, in the same order, as when it was fused into the cells), evaluated right
+    // behind its barrier; sets `n`: the number of following sweeps that cannot pass the test
+#define BCN_CHECK(SRC, DST, DST_IS_B)                                                        \
+    {                                                                                        \
+      BCN_CELLS(SRC, DST)                                                                    \
+      BCN_NCHK_INC                                                                           \
+      real acc = 0;                                                                          \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) { const real d = DST[k] - SRC[k]; acc += d * d; } \
+      const real pI = wl * acc;                                                              \
+      const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
+      const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
+      const real partu = acc + d0 * d0 + dl * dl;   /* lanes past the top row hold zeros */  \
+      const real tot63 = wave_sum_lane63<real>(part), totu63 = wave_sum_lane63<real>(partu); \
+      if (lane == 63) { errp[xb * 32 + w] = tot63; errp[xb * 32 + 16 + w] = totu63; }        \
+      real eB[NW], eU[NW];                                                                   \
+      __syncthreads();                                                                       \
+      itp++;                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < NW; q++) { eB[q] = errp[xb * 32 + q]; eU[q] = errp[xb * 32 + 16 + q]; } \
+      hWr = ex(xb, wm, 1)[lane];                                                             \
+      hEr = ex(xb, wp, 0)[lane];                                                             \
       xb ^= 1;                                                                               \
+      /* every lane sums the NW partials it read by broadcast, in a fixed order: uniform */  \
+      _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                   \
+        _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) { eB[q] += eB[q + st]; eU[q] += eU[q + st]; } \
+      const real err = read_lane(eB[0], 0);                                                  \
+      if (!(err > A.tol)) {                                                                  \
+        if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
+        finalB = DST_IS_B; break;                                                            \
+      }                                                                                      \
+      if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; }               \
+      n = 0;                                                                                 \
+      if (skip_left > 0) {                                                                   \
+        skip_left--;                                                                         \
+      } else if (A.conv_plan > 0) {   /* plan the next evaluation (see above) */             \
+        const float l2u = __log2f((float)read_lane(eU[0], 0)), l2w = __log2f((float)err);    \
+        int j = 0;                                                                           \
+        if (k_prev >= 0) {                                                                   \
+          const float rg = 1.f / (float)(itp - 1 - k_prev);                                  \
+          const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;                 \
+          if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
+          if (A.conv_plan > 1) {                                                             \
+            const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;               \
+            int jw = 0;                                                                      \
+            if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
+            jw -= 1 + (jw >> 4);                                                             \
+            j = jw > j ? jw : j;                                                             \
+          }                                                                                  \
+        }                                                                                    \
+        j = __builtin_amdgcn_readfirstlane(j);                                               \
+        l2u_prev = l2u; l2w_prev = l2w; k_prev = itp - 1;                                    \
+        if (A.verify_conv) skip_left = j; else n = j;                                        \
+      }                                                                                      \
     }
     for (;;) {
-      BCN_SWEEP(phA, phB, false)
-      BCN_SWEEP(phB, phA, true)
+      int n;
+      BCN_CHECK(phA, phB, true)
+      if (n == 0) {
+        BCN_CHECK(phB, phA, false)
+        n &= ~1;
+      } else {
+        BCN_FAST(phB, phA)
+        n = (n - 1) & ~1;
+      }
+      if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
+      for (; n > 0; n -= 2) {
+        BCN_FAST(phA, phB)
+        BCN_FAST(phB, phA)
+      }
     }
-#undef BCN_SWEEP
+#undef BCN_CHECK
+#undef BCN_FAST
+#undef BCN_SWEEP_END
+#undef BCN_CELLS
     if (finalB) {
 #pragma unroll
       for (int k = 0; k < R; k++) phA[k] = phB[k];
     }
+    hW = hWr;   // west halo of the final phi (read behind the last barrier; unused by wave 0)
 #ifdef BCN_STAMP   // diagnostic build only: cycles per sweep in the high half of the sweep count
     {
       const unsigned long long st1 = __builtin_amdgcn_s_memtime();
       const int cps = (int)((st1 - st0) / (unsigned long long)(itp > 0 ? itp : 1));
       if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp | (cps << 16);
     }
+#elif defined(BCN_DBG_NCHK)   // diagnostic build only: residual evaluations in the high half of the sweep count
+    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp | (nchk << 16);
 #else
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 #endif
@@ -549,7 +602,7 @@ __global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
-                                                          FastGeom<NX, NY, R, GF>::EXCH + 128);
+                                                          FastGeom<NX, NY, R, GF>::EXCH + 160);
   ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
     fast_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, it0, it1, first, last, smem);
   });
@@ -591,6 +644,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
+  if (const char* e = getenv("BCN_VERIFY_CONV")) c.verify_conv = atoi(e);
   const SchedParams sp = ns2d_sched_params(a);
   const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {

@@ -158,6 +158,10 @@ class VecEnv(object):
         results do not depend on it."""
         _lib.check(self.lib.bcn_set_sched(self.h, int(mode), int(grid), int(q), int(lpt_min_batch)))
 
+    def set_option(self, name, value):
+        """Solver options by name (include/beacon_hip.h: bcn_set_option), e.g. ("conv_plan", 0)."""
+        _lib.check(self.lib.bcn_set_option(self.h, name.encode(), int(value)))
+
     def get_counters(self):
         """uint64 [B, 2]: shader cycles of the last step inside the Jacobi loop / in the whole replica."""
         buf = (C.c_uint64 * (2 * self.batch))()

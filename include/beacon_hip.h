@@ -33,7 +33,8 @@ typedef struct bcn_env_s* bcn_env_t;
 enum { BCN_F32 = 0, BCN_F64 = 1 };
 enum { BCN_OK = 0, BCN_ERR_ARG = 1, BCN_ERR_HIP = 2, BCN_ERR_UNSUPPORTED = 3 };
 /* per-replica status word written by *_step */
-enum { BCN_ST_OK = 0, BCN_ST_ITMAX = 1, BCN_ST_BLOWUP = 2 };
+enum { BCN_ST_OK = 0, BCN_ST_ITMAX = 1, BCN_ST_BLOWUP = 2,
+       BCN_ST_PLAN = 4 /* diagnostic (BCN_VERIFY_CONV=1): a Jacobi sweep the residual-evaluation plan skips passed the test */ };
 /* env kinds (bcn_env_kind) */
 enum { BCN_RAYLEIGH = 0, BCN_MIXING = 1, BCN_BURGERS = 2, BCN_SHKADOV = 3, BCN_SLOSHING = 4 };
 
@@ -175,6 +176,14 @@ BCN_API int bcn_set_variant(bcn_env_t h, int variant);
  * inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463) and in the whole replica (all chunks),
  * uint64[B][2] on the host; zeros for kernels that do not count (generic 2D kernel, 1D envs). */
 BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
+/* Solver options of the 2D envs (no reference counterpart), by name:
+ *   "conv_plan"   which Jacobi sweeps evaluate the residual sum((phi - phin)^2) of rayleigh.py:448-449 / mixing.py:457-458
+ *                 in the register-resident kernels: 0 = every sweep, as the reference does; 1 = every sweep that can pass
+ *                 the test according to a proven lower bound of the norm (same stop sweep; default for BCN_F64);
+ *                 2 = additionally extrapolating the norm's observed decay (default for BCN_F32; see ns2d_fast.hip)
+ *   "verify_conv" 1 = evaluate every sweep anyway and raise BCN_ST_PLAN if a sweep the plan skips passes the test
+ * Returns BCN_ERR_ARG for unknown names. */
+BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference
  * counterpart: the reference steps one env per process, rayleigh.py:138-157).  mode: -1 = default
  * (environment BCN_SCHED, else 2), 0 = one workgroup per replica in one launch, 1 = two launches with the

@@ -83,6 +83,48 @@ __global__ __launch_bounds__(NW * 64) void sweepA(float* out, const float* in, i
   out[(blockIdx.x * 1024 + tid) % (256 * 512)] = r;
 }
 
+// ---- A0 with s_memtime stamps (diagnostic): where does a sweep's time go?  segments: after barrier -> interior cells
+// done and LDS reads arrived | -> edge cells, reduction, LDS stores issued and drained | -> through the barrier
+__global__ __launch_bounds__(512) void sweepA_stamp(float* out, const float* in, int nsweep, float cx, unsigned long long* seg_out) {
+  constexpr int R = 16, NW = 8, VAR = 0;
+  __shared__ float ex[2][NW][2][64];
+  __shared__ __attribute__((aligned(16))) float errp[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float A[R], B[R], nb[R];
+  for (int k = 0; k < R; k++) { A[k] = 0; nb[k] = in[((blockIdx.x * 1024 + tid) * 16 + k) % (256 * 512 * 16)]; }
+  const float cB = (lane == 0 || lane == 63) ? cx : 0.f, wl = 1.f + (lane == 0) + (lane == 63);
+  const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
+  float hW = 0, hE = 0, hWr = 0, hEr = 0, e8[NW], errsum = 0;
+  for (int q = 0; q < NW; q++) e8[q] = 0;
+  int xb = 0;
+  unsigned long long seg[3] = {0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[i] += t_ - tl; tl = t_; __builtin_amdgcn_sched_barrier(0); }
+#define SWEEPS(S, D)                                                                     \
+  {                                                                                      \
+    float acc = 0;                                                                       \
+    _Pragma("unroll") for (int k = 1; k < R - 1; k++) { float ph = CELLA(S[k], S[k + 1], S[k - 1], nb[k]); float d = ph - S[k]; acc += d * d; D[k] = ph; } \
+    const float pI = wl * acc;                                                           \
+    STAMP(0)                                                                             \
+    { _Pragma("unroll") for (int st = 1; st < NW; st *= 2) _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) e8[q] += e8[q + st]; \
+      errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e8[0]), 0)); } \
+    hW = (w > 0) ? hWr : S[0]; hE = (w < NW - 1) ? hEr : S[R - 1];                       \
+    float p0 = CELLA(S[0], S[1], hW, nb[0]), pl = CELLA(S[R - 1], hE, S[R - 2], nb[R - 1]); \
+    float d0 = p0 - S[0], dl = pl - S[R - 1]; D[0] = p0; D[R - 1] = pl;                  \
+    float tot = wave_sum63(pI + wl * (d0 * d0) + wl * (dl * dl));                        \
+    ex[xb][w][0][lane] = p0; ex[xb][w][1][lane] = pl; if (lane == 63) errp[xb][w] = tot; \
+    STAMP(1)                                                                             \
+    __syncthreads();                                                                     \
+    _Pragma("unroll") for (int q = 0; q < NW; q++) e8[q] = errp[xb][q];                  \
+    hWr = ex[xb][wm][1][lane]; hEr = ex[xb][wp][0][lane]; xb ^= 1;                       \
+    STAMP(2)                                                                             \
+  }
+  for (int it = 0; it < nsweep; it += 2) { SWEEPS(A, B) SWEEPS(B, A) }
+  float r = errsum;
+  for (int k = 0; k < R; k++) r += A[k];
+  out[(blockIdx.x * 1024 + tid) % (256 * 512)] = r;
+  if (lane == 0 && blockIdx.x == 0) for (int q = 0; q < 3; q++) seg_out[w * 3 + q] = seg[q] / nsweep;
+}
+
 // ---- B: lanes along x, two columns per lane, 8 rows per wave -----------------------------------
 __global__ __launch_bounds__(512) void sweepB(float* out, const float* in, int nsweep, float cx) {
   constexpr int NR = 8, NW = 8;   // rows per wave; cell (r, c): row w*8 + r, column 2*lane + c
@@ -193,6 +235,13 @@ __global__ __launch_bounds__(512) void sweepC(float* out, const float* in, int n
 //     each of its first interior cells, and published before that sweep's barrier: the convergence decision about
 //     sweep k is taken early in sweep k+2 (phi rotates through three arrays so that phi_k is still intact then);
 //     LAG = 0: reduction at the end of the sweep as in A (two arrays).
+#define RED_STEP(r, CTRL) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(r))
+__device__ __forceinline__ float red_bcast(float r, int which) {   // row_bcast:15 (rows 1,3) / row_bcast:31 (rows 2,3), behind s_nop 1
+  float t = 0;
+  if (which == 0) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t) : "v"(r));
+  else asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t) : "v"(r));
+  return r + t;
+}
 template <int LAG, int H>
 __global__ __launch_bounds__(512) void sweepD(float* out, const float* in, int nsweep, float cx) {
   constexpr int R = 16, NW = 8;
@@ -213,13 +262,21 @@ __global__ __launch_bounds__(512) void sweepD(float* out, const float* in, int n
     float acc = 0, red = ppart;                                                          \
     _Pragma("unroll") for (int k = 1; k <= H; k++) {                                     \
       INTERIOR(S, D, k)                                                                  \
-      if (LAG) {                                                                         \
+      if (LAG == 1) {                                                                    \
         if (k == 1) red += dppf<0x111, 0xf>(red);                                        \
         if (k == 2) red += dppf<0x112, 0xf>(red);                                        \
         if (k == 3) red += dppf<0x114, 0xf>(red);                                        \
         if (k == 4) red += dppf<0x118, 0xf>(red);                                        \
         if (k == 5) red += dppf<0x142, 0xa>(red);                                        \
         if (k == 6) red += dppf<0x143, 0xc>(red);                                        \
+      }                                                                                  \
+      if (LAG == 2) {   /* the same steps as inline asm behind s_nop 1 */                \
+        if (k == 1) RED_STEP(red, "row_shr:1");                                          \
+        if (k == 2) RED_STEP(red, "row_shr:2");                                          \
+        if (k == 3) RED_STEP(red, "row_shr:4");                                          \
+        if (k == 4) RED_STEP(red, "row_shr:8");                                          \
+        if (k == 5) red = red_bcast(red, 0);                                             \
+        if (k == 6) red = red_bcast(red, 1);                                             \
       }                                                                                  \
     }                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                   \
@@ -245,6 +302,104 @@ __global__ __launch_bounds__(512) void sweepD(float* out, const float* in, int n
   out[(blockIdx.x * 1024 + tid) % (256 * 512)] = r;
 }
 
+// ---- E: mapping A with the cell arithmetic in hand-ordered inline-asm blocks of 4 / 3 / 2 cells: the same seven
+// instructions per cell as A0 (add, 2 fused DPP adds, ghost fma, cx fmac, difference, residual fmac -- bit-identical
+// results), but interleaved across the cells of a block so that no DPP add directly follows its producer: no s_nop,
+// no dependent-DPP stall; the two edge cells sit in the middle of the sweep (halo reads covered by the first 7
+// interior cells, their stores by the last 7); the exchange buffers are addressed with compile-time parity.
+#define DPP_UP " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define DPP_DN " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+__device__ __forceinline__ void cells4(float& d0, float& d1, float& d2, float& d3, float sm, float s0, float s1, float s2,
+                                       float s3, float sp, float n0, float n1, float n2, float n3, float cB, float cx, float& acc) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_add_f32 %[t0], %[s1], %[sm]\n v_add_f32 %[t1], %[s2], %[s0]\n v_add_f32 %[t2], %[s3], %[s1]\n v_add_f32 %[t3], %[sp], %[s2]\n"
+      "v_fma_f32 %[d0], %[cB], %[s0], %[n0]\n v_fma_f32 %[d1], %[cB], %[s1], %[n1]\n v_fma_f32 %[d2], %[cB], %[s2], %[n2]\n v_fma_f32 %[d3], %[cB], %[s3], %[n3]\n"
+      "v_add_f32_dpp %[t0], %[s0], %[t0]" DPP_UP "v_add_f32_dpp %[t1], %[s1], %[t1]" DPP_UP "v_add_f32_dpp %[t2], %[s2], %[t2]" DPP_UP "v_add_f32_dpp %[t3], %[s3], %[t3]" DPP_UP
+      "v_add_f32_dpp %[t0], %[s0], %[t0]" DPP_DN "v_add_f32_dpp %[t1], %[s1], %[t1]" DPP_DN "v_add_f32_dpp %[t2], %[s2], %[t2]" DPP_DN "v_add_f32_dpp %[t3], %[s3], %[t3]" DPP_DN
+      "v_fmac_f32 %[d0], %[cx], %[t0]\n v_fmac_f32 %[d1], %[cx], %[t1]\n v_fmac_f32 %[d2], %[cx], %[t2]\n v_fmac_f32 %[d3], %[cx], %[t3]\n"
+      "v_sub_f32 %[t0], %[d0], %[s0]\n v_sub_f32 %[t1], %[d1], %[s1]\n v_sub_f32 %[t2], %[d2], %[s2]\n v_sub_f32 %[t3], %[d3], %[s3]\n"
+      "v_fmac_f32 %[acc], %[t0], %[t0]\n v_fmac_f32 %[acc], %[t1], %[t1]\n v_fmac_f32 %[acc], %[t2], %[t2]\n v_fmac_f32 %[acc], %[t3], %[t3]\n"
+      : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        [t3] "=&v"(t3), [acc] "+v"(acc)
+      : [sm] "v"(sm), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [sp] "v"(sp), [n0] "v"(n0), [n1] "v"(n1),
+        [n2] "v"(n2), [n3] "v"(n3), [cB] "v"(cB), [cx] "s"(cx));
+}
+__device__ __forceinline__ void cells3(float& d0, float& d1, float& d2, float sm, float s0, float s1, float s2, float sp,
+                                       float n0, float n1, float n2, float cB, float cx, float& acc) {
+  float t0, t1, t2;
+  asm volatile(
+      "v_add_f32 %[t0], %[s1], %[sm]\n v_add_f32 %[t1], %[s2], %[s0]\n v_add_f32 %[t2], %[sp], %[s1]\n"
+      "v_fma_f32 %[d0], %[cB], %[s0], %[n0]\n v_fma_f32 %[d1], %[cB], %[s1], %[n1]\n v_fma_f32 %[d2], %[cB], %[s2], %[n2]\n"
+      "v_add_f32_dpp %[t0], %[s0], %[t0]" DPP_UP "v_add_f32_dpp %[t1], %[s1], %[t1]" DPP_UP "v_add_f32_dpp %[t2], %[s2], %[t2]" DPP_UP
+      "v_add_f32_dpp %[t0], %[s0], %[t0]" DPP_DN "v_add_f32_dpp %[t1], %[s1], %[t1]" DPP_DN "v_add_f32_dpp %[t2], %[s2], %[t2]" DPP_DN
+      "v_fmac_f32 %[d0], %[cx], %[t0]\n v_fmac_f32 %[d1], %[cx], %[t1]\n v_fmac_f32 %[d2], %[cx], %[t2]\n"
+      "v_sub_f32 %[t0], %[d0], %[s0]\n v_sub_f32 %[t1], %[d1], %[s1]\n v_sub_f32 %[t2], %[d2], %[s2]\n"
+      "v_fmac_f32 %[acc], %[t0], %[t0]\n v_fmac_f32 %[acc], %[t1], %[t1]\n v_fmac_f32 %[acc], %[t2], %[t2]\n"
+      : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [acc] "+v"(acc)
+      : [sm] "v"(sm), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [sp] "v"(sp), [n0] "v"(n0), [n1] "v"(n1), [n2] "v"(n2),
+        [cB] "v"(cB), [cx] "s"(cx));
+}
+// the two strip-edge cells: (s0; east s1, west hW) and (sl; east hE, west sl1); returns the new values and differences
+__device__ __forceinline__ void cells_edge(float& p0, float& pl, float& df0, float& dfl, float s0, float s1, float hW, float n0,
+                                           float sl, float hE, float sl1, float nl, float cB, float cx) {
+  float t0, t1;
+  asm volatile(
+      "v_add_f32 %[t0], %[s1], %[hW]\n v_add_f32 %[t1], %[hE], %[sl1]\n"
+      "v_fma_f32 %[p0], %[cB], %[s0], %[n0]\n v_fma_f32 %[pl], %[cB], %[sl], %[nl]\n"
+      "v_add_f32_dpp %[t0], %[s0], %[t0]" DPP_UP "v_add_f32_dpp %[t1], %[sl], %[t1]" DPP_UP
+      "v_add_f32_dpp %[t0], %[s0], %[t0]" DPP_DN "v_add_f32_dpp %[t1], %[sl], %[t1]" DPP_DN
+      "v_fmac_f32 %[p0], %[cx], %[t0]\n v_fmac_f32 %[pl], %[cx], %[t1]\n"
+      "v_sub_f32 %[df0], %[p0], %[s0]\n v_sub_f32 %[dfl], %[pl], %[sl]\n"
+      : [p0] "=&v"(p0), [pl] "=&v"(pl), [df0] "=&v"(df0), [dfl] "=&v"(dfl), [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [s0] "v"(s0), [s1] "v"(s1), [hW] "v"(hW), [n0] "v"(n0), [sl] "v"(sl), [hE] "v"(hE), [sl1] "v"(sl1), [nl] "v"(nl),
+        [cB] "v"(cB), [cx] "s"(cx));
+}
+
+template <int EDGE_MID>
+__global__ __launch_bounds__(512) void sweepE(float* out, const float* in, int nsweep, float cx) {
+  constexpr int R = 16, NW = 8;
+  __shared__ float ex[2][NW][2][64];
+  __shared__ __attribute__((aligned(16))) float errp[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float A[R], B[R], nb[R];
+  for (int k = 0; k < R; k++) { A[k] = 0; B[k] = 0; nb[k] = in[((blockIdx.x * 1024 + tid) * 16 + k) % (256 * 512 * 16)]; }
+  const float cB = (lane == 0 || lane == 63) ? cx : 0.f, wl = 1.f + (lane == 0) + (lane == 63);
+  const int wm = w > 0 ? w - 1 : 0, wp = w < NW - 1 ? w + 1 : NW - 1;
+  float hWr = 0, hEr = 0, e8[NW], errsum = 0;
+  for (int q = 0; q < NW; q++) e8[q] = 0;
+#define SWEEPE(S, D, XB)                                                                 \
+  {                                                                                      \
+    float acc = 0, p0, pl, d0, dl;                                                       \
+    cells4(D[1], D[2], D[3], D[4], S[0], S[1], S[2], S[3], S[4], S[5], nb[1], nb[2], nb[3], nb[4], cB, cx, acc); \
+    cells3(D[5], D[6], D[7], S[4], S[5], S[6], S[7], S[8], nb[5], nb[6], nb[7], cB, cx, acc);                 \
+    if (EDGE_MID) {                                                                      \
+      const float hW = (w > 0) ? hWr : S[0], hE = (w < NW - 1) ? hEr : S[R - 1];         \
+      cells_edge(p0, pl, d0, dl, S[0], S[1], hW, nb[0], S[R - 1], hE, S[R - 2], nb[R - 1], cB, cx); \
+      ex[XB][w][0][lane] = p0; ex[XB][w][1][lane] = pl;                                  \
+    }                                                                                    \
+    cells4(D[8], D[9], D[10], D[11], S[7], S[8], S[9], S[10], S[11], S[12], nb[8], nb[9], nb[10], nb[11], cB, cx, acc); \
+    cells3(D[12], D[13], D[14], S[11], S[12], S[13], S[14], S[15], nb[12], nb[13], nb[14], cB, cx, acc);      \
+    { _Pragma("unroll") for (int st = 1; st < NW; st *= 2) _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) e8[q] += e8[q + st]; \
+      errsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e8[0]), 0)); } \
+    if (!EDGE_MID) {                                                                     \
+      const float hW = (w > 0) ? hWr : S[0], hE = (w < NW - 1) ? hEr : S[R - 1];         \
+      cells_edge(p0, pl, d0, dl, S[0], S[1], hW, nb[0], S[R - 1], hE, S[R - 2], nb[R - 1], cB, cx); \
+      ex[XB][w][0][lane] = p0; ex[XB][w][1][lane] = pl;                                  \
+    }                                                                                    \
+    D[0] = p0; D[R - 1] = pl;                                                            \
+    const float tot = wave_sum63(wl * acc + wl * (d0 * d0) + wl * (dl * dl));            \
+    if (lane == 63) errp[XB][w] = tot;                                                   \
+    __syncthreads();                                                                     \
+    _Pragma("unroll") for (int q = 0; q < NW; q++) e8[q] = errp[XB][q];                  \
+    hWr = ex[XB][wm][1][lane]; hEr = ex[XB][wp][0][lane];                                \
+  }
+  for (int it = 0; it < nsweep; it += 2) { SWEEPE(A, B, 0) SWEEPE(B, A, 1) }
+  float r = errsum;
+  for (int k = 0; k < R; k++) r += A[k] + B[k];
+  out[(blockIdx.x * 1024 + tid) % (256 * 512)] = r;
+}
+
 int main() {
   const int nwg = 256, nsweep = 4000;
   float *in, *out;
@@ -257,14 +412,14 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   int clk = 0;
   hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
-  const char* names[20] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
+  const char* names[24] = {"A0 lanes along y, fused DPP pair (kernel)", "A1 compiler-scheduled DPP builtins", "A2 two v_mov_dpp + plain adds",
                           "A3 two independent fused DPP adds", "B  lanes along x, 1 DPP per cell", "C  A0 with two sweeps per barrier (depth-2 halos)",
                           "A0 with 16 waves x 8 columns", "A0 with 4 waves x 32 columns", "A0 with 12 waves x 11 columns (132 columns: x 0.97)",
                           "A0 with 13 waves x 10 columns (130 columns)", "A0 with 10 waves x 13 columns (130 columns)",
                           "A4 two residual accumulators", "A5 no sched_barrier", "A6 no interior residual (floor, wrong)",
-                          "D  edges mid-sweep (H=6), reduction at the end", "D  edges mid-sweep (H=6), LAGGED reduction, 3 arrays", "D  edges mid-sweep (H=8), LAGGED reduction", "D  edges mid-sweep (H=4), reduction at the end", "D edges mid-sweep (H=10), LAGGED", "D edges at end (H=14), LAGGED"};
+                          "D  edges mid-sweep (H=6), reduction at the end", "D  edges mid-sweep (H=6), LAGGED reduction, 3 arrays", "D  edges mid-sweep (H=8), LAGGED reduction", "D  edges mid-sweep (H=4), reduction at the end", "D edges mid-sweep (H=10), LAGGED", "D edges at end (H=14), LAGGED", "E  asm cell blocks, edges mid-sweep", "E  asm cell blocks, edges at the end", "D  edges mid (H=6), LAGGED, reduction steps behind s_nop 1", "D  edges mid (H=8), LAGGED, reduction steps behind s_nop 1"};
   for (int rep = 0; rep < 2; rep++)
-    for (int v = 0; v < 20; v++) {
+    for (int v = 0; v < 24; v++) {
       hipEventRecord(e0);
       if (v == 0) hipLaunchKernelGGL(sweepA<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 1) hipLaunchKernelGGL(sweepA<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
@@ -281,6 +436,10 @@ int main() {
       if (v == 17) hipLaunchKernelGGL((sweepD<0, 4>), dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
       if (v == 18) hipLaunchKernelGGL((sweepD<1, 10>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
       if (v == 19) hipLaunchKernelGGL((sweepD<1, 14>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
+      if (v == 20) hipLaunchKernelGGL(sweepE<1>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 21) hipLaunchKernelGGL(sweepE<0>, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f);
+      if (v == 22) hipLaunchKernelGGL((sweepD<2, 6>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
+      if (v == 23) hipLaunchKernelGGL((sweepD<2, 8>), dim3(nwg), dim3(512), 0, 0, out, in, 3999, 0.25f);
       if (v == 6) hipLaunchKernelGGL((sweepA<0, 8, 16>), dim3(nwg), dim3(1024), 0, 0, out, in, nsweep, 0.25f);
       if (v == 7) hipLaunchKernelGGL((sweepA<0, 32, 4>), dim3(nwg), dim3(256), 0, 0, out, in, nsweep, 0.25f);
       if (v == 8) hipLaunchKernelGGL((sweepA<0, 11, 12>), dim3(nwg), dim3(768), 0, 0, out, in, nsweep, 0.25f);
@@ -290,5 +449,11 @@ int main() {
       float ms = 0; hipEventElapsedTime(&ms, e0, e1);
       if (rep) printf("%-45s %.0f ns per sweep = ~%.0f cycles at %.2f GHz (max clock)\n", names[v], ms * 1e6 / nsweep, ms * 1e6 / nsweep * (clk * 1e-6), clk * 1e-6);
     }
+  {
+    unsigned long long* sg; hipMalloc(&sg, 24 * 8);
+    hipLaunchKernelGGL(sweepA_stamp, dim3(nwg), dim3(512), 0, 0, out, in, nsweep, 0.25f, sg);
+    unsigned long long h[24]; hipMemcpy(h, sg, sizeof(h), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 8; w++) printf("stamped A0, wave %d: cells+reads %llu | edges+reduce+stores %llu | barrier+read issue %llu cycles per sweep\n", w, h[3 * w], h[3 * w + 1], h[3 * w + 2]);
+  }
   return 0;
 }

@@ -487,6 +487,60 @@ def test_rayleigh_bench_episode_is_deterministic_with_staggered_resets():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+def test_convergence_plan_never_skips_a_passing_sweep():
+    """The register-resident kernels evaluate the Jacobi residual only on the sweeps that can pass the test
+    (ns2d_fast.hip: a proven lower bound of the norm, conv_plan 1, the float64 default; plus an extrapolation of the
+    norm's observed decay, conv_plan 2, the float32 default).  "verify_conv" evaluates every sweep and raises
+    BCN_ST_PLAN (4) if a sweep the plan would have skipped passes: it must never do so, and sweep counts and fields must
+    equal those of the planned run and of conv_plan 0 (every sweep evaluated, as the reference does) bit for bit --
+    bench workload (B=512, f32, 2 steps = 205 000 solves), the reference's 50x50 vectors (f64) and the synthetic 128x64
+    state whose first solve takes 5375 sweeps."""
+    def run(verify, plan=None):
+        out = []
+        env, init, acts = _bench_workload(512, 2, "f32")
+        env.set_option("verify_conv", verify)
+        if plan is not None:
+            env.set_option("conv_plan", plan)
+        for k in range(2):
+            env.step(acts[k])
+        out.append((env.status.clone(), env.sweeps.clone(), env.get_state().clone()))
+        env.close()
+        g = golden("rayleigh_default")
+        for p in ([plan] if plan is not None else [1, 2]):
+            env = V.VecRayleigh(4, DEV, "f64", _ray_init(g))
+            _variant(env, 1)
+            env.set_option("verify_conv", verify)
+            env.set_option("conv_plan", p)
+            env.reset()
+            for k in range(2):
+                env.step(np.tile(g["actions"][k], (4, 1)))
+            assert np.array_equal(env.sweeps.cpu().numpy()[0], g["itp"][1])
+            out.append((env.status.clone(), env.sweeps.clone(), env.get_state().clone()))
+            env.close()
+        g = golden("rayleigh_128x64")
+        for p in ([plan] if plan is not None else [1, 2]):
+            env = V.VecRayleigh(2, DEV, "f64", None, L=2.56, H=1.28)
+            env.set_ndt_act(5)
+            _variant(env, 1)
+            env.set_option("verify_conv", verify)
+            env.set_option("conv_plan", p)
+            env.reset()
+            st0 = np.stack([ref_to_dev(g[k]) for k in ("u0", "v0", "p0", "T0")])
+            env.set_state(np.tile(st0[None], (2, 1, 1, 1)))
+            env.step(np.tile(g["actions"][0], (2, 1)))
+            assert np.array_equal(env.sweeps.cpu().numpy()[0], g["itp"][0])
+            out.append((env.status.clone(), env.sweeps.clone(), env.get_state().clone()))
+            env.close()
+        return out
+    planned, verified = run(0), run(1)
+    for (st_p, sw_p, f_p), (st_v, sw_v, f_v) in zip(planned, verified):
+        assert int(st_v.max()) == 0 and int(st_p.max()) == 0          # no BCN_ST_PLAN, no overflow
+        assert torch.equal(sw_p, sw_v) and torch.equal(f_p, f_v)
+    literal = run(0, plan=0)                                          # every sweep evaluated, as the reference does
+    for i, j in ((0, 0), (1, 1), (2, 1), (3, 2), (4, 2)):
+        assert torch.equal(planned[i][1], literal[j][1]) and torch.equal(planned[i][2], literal[j][2])
+
+
 @pytest.mark.parametrize("L,nx", [(2.0, 100), (3.0, 150), (4.0, 200)])
 def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
     """Register-resident instantiations for the reference's other natural aspect ratios (nx = 50 L, ny = 50):
