@@ -343,10 +343,10 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
     // interior: err = d'(I+G)d >= a).  While a_k rho^i > 1.02 tol the test cannot pass, and those sweeps run WITHOUT
     // the residual (5 instead of 7 instructions per cell, no wave reduction, no partials through LDS).
     // A.conv_plan: 0 = evaluate every sweep (the reference, literally); 1 = skip only what the bound above proves
-    // (exact stop sweep: the float64 default); 2 = additionally extrapolate the reference norm itself, whose decay
-    // factor is observed -- not proven: I+G does not commute with J -- never to decrease either (10 000 sweeps of
-    // oracle traces, scripts/plan_sim.py), stopping the skip 1 + 1/16 of its length early (the float32 default: the
-    // evaluations drop from ~28 % to ~10 % of the sweeps).  A.verify_conv evaluates every sweep anyway and raises
+    // (exact stop sweep: the float64 default); 2 = extrapolate the reference norm itself instead, whose decay factor is
+    // observed -- not proven: I+G does not commute with J -- never to decrease either (10 000 sweeps of oracle traces,
+    // scripts/plan_sim.py), ending the skip 1 + 1/16 of its length early (the float32 default: the evaluations drop
+    // from ~28 % to ~9 % of the sweeps).  A.verify_conv evaluates every sweep anyway and raises
     // BCN_ST_PLAN if a sweep the plan would have skipped passes the test (tests/test_gpu_parity.py).
     auto cell = [&](real c, real e, real wv, real nbk) -> real {
       const real q = cBy * c + nbk;                       // Neumann ghosts in y copy the cell itself
@@ -418,19 +418,24 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       const real pI = wl * acc;                                                              \
       const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
       const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
-      const real partu = acc + d0 * d0 + dl * dl;   /* lanes past the top row hold zeros */  \
-      const real tot63 = wave_sum_lane63<real>(part), totu63 = wave_sum_lane63<real>(partu); \
-      if (lane == 63) { errp[xb * 32 + w] = tot63; errp[xb * 32 + 16 + w] = totu63; }        \
+      const real tot63 = wave_sum_lane63<real>(part);                                        \
+      if (lane == 63) errp[xb * 32 + w] = tot63;                                             \
+      if (A.conv_plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
+        const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + dl * dl);                  \
+        if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                     \
+      }                                                                                      \
       real eB[NW], eU[NW];                                                                   \
       __syncthreads();                                                                       \
       itp++;                                                                                 \
-      _Pragma("unroll") for (int q = 0; q < NW; q++) { eB[q] = errp[xb * 32 + q]; eU[q] = errp[xb * 32 + 16 + q]; } \
+      _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 32 + q];              \
+      if (A.conv_plan == 1) { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = errp[xb * 32 + 16 + q]; } \
+      else { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = 0; }                     \
       hWr = ex(xb, wm, 1)[lane];                                                             \
       hEr = ex(xb, wp, 0)[lane];                                                             \
       xb ^= 1;                                                                               \
       /* every lane sums the NW partials it read by broadcast, in a fixed order: uniform */  \
       _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                   \
-        _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) { eB[q] += eB[q + st]; eU[q] += eU[q + st]; } \
+        _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st];     \
       const real err = read_lane(eB[0], 0);                                                  \
       if (!(err > A.tol)) {                                                                  \
         if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
@@ -441,18 +446,25 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
       if (skip_left > 0) {                                                                   \
         skip_left--;                                                                         \
       } else if (A.conv_plan > 0) {   /* plan the next evaluation (see above) */             \
-        const float l2u = __log2f((float)read_lane(eU[0], 0)), l2w = __log2f((float)err);    \
+        float l2u = 0;                                                                       \
+        if (A.conv_plan == 1) {                                                              \
+          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                               \
+            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eU[q] += eU[q + st]; \
+          l2u = __log2f((float)read_lane(eU[0], 0));                                         \
+        }                                                                                    \
+        const float l2w = __log2f((float)err);                                               \
         int j = 0;                                                                           \
         if (k_prev >= 0) {                                                                   \
           const float rg = 1.f / (float)(itp - 1 - k_prev);                                  \
-          const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;                 \
-          if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
-          if (A.conv_plan > 1) {                                                             \
+          if (A.conv_plan == 1) {                                                            \
+            const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;               \
+            if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
+          } else {                                                                           \
             const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;               \
             int jw = 0;                                                                      \
             if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
-            jw -= 1 + (jw >> 4);                                                             \
-            j = jw > j ? jw : j;                                                             \
+            j = jw - 1 - (jw >> 4);                                                          \
+            j = j > 0 ? j : 0;                                                               \
           }                                                                                  \
         }                                                                                    \
         j = __builtin_amdgcn_readfirstlane(j);                                               \

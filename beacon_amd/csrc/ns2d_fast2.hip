@@ -17,6 +17,8 @@
 //     its rows per step; the west values stay in registers, the south value of the lower row comes
 //     from the lane below by DPP (transport_chain2).
 // Semantics and citations: ns2d_generic.hip.  Plain launch, one workgroup per replica.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "bcn_dpp.h"
@@ -39,9 +41,9 @@ struct Fast2Geom {
   static constexpr int SY = NY + 2;
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY;
-  // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 32 | sact 64 | red 32 | U V S
+  // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 64 | sact 64 | red 32 | U V S
   static constexpr int EXCH = 2 * NW * 4 * 64;
-  static constexpr size_t lds_elems() { return (size_t)EXCH + 128 + 3 * (size_t)SZ; }
+  static constexpr size_t lds_elems() { return (size_t)EXCH + 160 + 3 * (size_t)SZ; }
 };
 
 // Ordered part of the transport step by ONE wave (out of line, see ns2d_fast.hip).  At step t lane l
@@ -98,8 +100,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   using G = Fast2Geom<NX, NY, R>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, LH = G::LH;
   real* exch = reinterpret_cast<real*>(smem);
-  real* errp = exch + G::EXCH;   // [2][16]
-  real* sact = errp + 32;        // [64]
+  real* errp = exch + G::EXCH;   // [2][2][16]: reference norm / unweighted norm partials
+  real* sact = errp + 64;        // [64]
   real* red = sact + 64;         // [32]
   real* Ul = red + 32;
   real* Vl = Ul + SZ;
@@ -126,7 +128,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     Vl[ii * SY + jj] = gv[c];
     Tl[ii * SY + jj] = gS[c];
   }
-  if (tid < 32) errp[tid] = 0;
+  if (tid < 64) errp[tid] = 0;
   real p[2][RW];
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -308,15 +310,22 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     BCN_PH(1)
     const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
     // ---- Jacobi sweeps: one barrier per sweep, phi ping-pong in registers ---------------------
+    // The residual is evaluated only on the sweeps that can pass the test (A.conv_plan, see ns2d_fast.hip); a sweep
+    // that evaluates it does so behind its own barrier, with the arithmetic the fused form had.
     real phA[2][RW], phB[2][RW];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int k = 0; k < RW; k++) phA[a][k] = 0;
     real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
-    real eB[NW], hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
+    real hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
     int itp = 0;
     bool finalB = false;
+    int k_prev = -1;
+    float l2u_prev = 0, l2w_prev = 0;
+    int skip_left = 0;
+    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+    constexpr int JMAX = 256;
     // lower row (a = 0): south = lane below's upper row (DPP), north = own upper row;
     // upper row (a = 1): south = own lower row, north = lane above's lower row (DPP)
 #define BCN_CELL(DST, SRC, K, EV, WV)                                                                \
@@ -324,49 +333,24 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       const real c0 = SRC[0][K], c1 = SRC[1][K];                                                     \
       real sn0, sn1;   /* south + north of the lower / upper row */                                  \
       add_pair_neighbours(c0, c1, sn0, sn1);                                                         \
-      real ph0, ph1;                                                                                 \
       if (EQ) {                                                                                      \
-        ph0 = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + nb[0][K]);                                 \
-        ph1 = cxl * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                                 \
+        DST[0][K] = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + nb[0][K]);                           \
+        DST[1][K] = cxl * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                           \
       } else {                                                                                       \
-        ph0 = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + nb[0][K]));                           \
-        ph1 = cxl * (EV##1 + WV##1) + (cyl * sn1 + (cB1 * c1 + nb[1][K]));                           \
+        DST[0][K] = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + nb[0][K]));                     \
+        DST[1][K] = cxl * (EV##1 + WV##1) + (cyl * sn1 + (cB1 * c1 + nb[1][K]));                     \
       }                                                                                              \
-      const real d0 = ph0 - c0, d1 = ph1 - c1;                                                       \
-      if (K == 0) { dW0 = d0 * d0; dW1 = d1 * d1; }                                                  \
-      else if (K == RW - 1) { dE0 = d0 * d0; dE1 = d1 * d1; }                                        \
-      else { acc0 += d0 * d0; acc1 += d1 * d1; }                                                     \
-      DST[0][K] = ph0;                                                                               \
-      DST[1][K] = ph1;                                                                               \
     }
-#ifndef BCN2_ERRB
-#define BCN2_ERRB 0   // 1: broadcast-read the NW error partials and add them per lane; 0: DPP row reduction (measured faster here)
-#endif
-#define BCN_SWEEP(SRC, DST, SRC_IS_B)                                                                \
-    {                                                                                                \
-      real acc0 = 0, acc1 = 0, dW0 = 0, dW1 = 0, dE0 = 0, dE1 = 0;                                   \
+#define BCN_CELLS(SRC, DST)                                                                          \
       _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
         const real e0 = SRC[0][k + 1], e1 = SRC[1][k + 1], w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];  \
         BCN_CELL(DST, SRC, k, e, w)                                                                  \
       }                                                                                              \
-      const real pI = wl0 * acc0 + wl1 * acc1;   /* the edge columns join below: short tail */        \
       __builtin_amdgcn_sched_barrier(0);   /* halo-dependent part stays behind the interior cells */ \
-      if (itp > 0) {                                                                                 \
-        real err;                                                                                    \
-        if (BCN2_ERRB) { /* every lane adds the NW partials it read by broadcast */                  \
-          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                       \
-            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st];         \
-          err = read_lane(eB[0], 0);                                                                 \
-        } else {                                                                                     \
-          err = read_lane(row16_sum<real>(eB[0]), 15);                                               \
-        }                                                                                            \
-        hW0 = (w > 0) ? hW0r : SRC[0][0];                                                            \
-        hW1 = (w > 0) ? hW1r : SRC[1][0];                                                            \
-        hE0 = (w < NW - 1) ? hE0r : SRC[0][RW - 1];                                                   \
-        hE1 = (w < NW - 1) ? hE1r : SRC[1][RW - 1];                                                   \
-        if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = SRC_IS_B; break; }                     \
-        if (!(err > A.tol)) { finalB = SRC_IS_B; break; }                                            \
-      }                                                                                              \
+      hW0 = (w > 0) ? hW0r : SRC[0][0];                                                              \
+      hW1 = (w > 0) ? hW1r : SRC[1][0];                                                              \
+      hE0 = (w < NW - 1) ? hE0r : SRC[0][RW - 1];                                                     \
+      hE1 = (w < NW - 1) ? hE1r : SRC[1][RW - 1];                                                     \
       {                                                                                              \
         const real e0 = SRC[0][1], e1 = SRC[1][1], w0 = hW0, w1 = hW1;                               \
         BCN_CELL(DST, SRC, 0, e, w)                                                                  \
@@ -375,31 +359,93 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         const real e0 = hE0, e1 = hE1, w0 = SRC[0][RW - 2], w1 = SRC[1][RW - 2];                       \
         BCN_CELL(DST, SRC, RW - 1, e, w)                                                              \
       }                                                                                              \
-      const real part = pI + (cW0 * dW0 + cW1 * dW1) + (cE0 * dE0 + cE1 * dE1);                      \
-      const real tot63 = wave_sum_lane63<real>(part);                                                \
       ex(xb, w, 0, 0)[lane] = DST[0][0];                                                             \
       ex(xb, w, 0, 1)[lane] = DST[1][0];                                                             \
       ex(xb, w, 1, 0)[lane] = DST[0][RW - 1];                                                         \
-      ex(xb, w, 1, 1)[lane] = DST[1][RW - 1];                                                         \
-      if (lane == 63) errp[xb * 16 + w] = tot63;                                                     \
-      __syncthreads();                                                                               \
-      itp++;                                                                                         \
-      if (BCN2_ERRB) {                                                                               \
-        _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 16 + q];                    \
-      } else {                                                                                       \
-        eB[0] = errp[xb * 16 + (lane & 15)];                                                         \
-      }                                                                                              \
+      ex(xb, w, 1, 1)[lane] = DST[1][RW - 1];
+#define BCN_HALO_READS                                                                               \
       hW0r = ex(xb, wm, 1, 0)[lane];                                                                 \
       hW1r = ex(xb, wm, 1, 1)[lane];                                                                 \
       hE0r = ex(xb, wp, 0, 0)[lane];                                                                 \
       hE1r = ex(xb, wp, 0, 1)[lane];                                                                 \
-      xb ^= 1;                                                                                       \
+      xb ^= 1;
+#define BCN_FAST(SRC, DST) { BCN_CELLS(SRC, DST) __syncthreads(); itp++; BCN_HALO_READS }
+#define BCN_CHECK(SRC, DST, DST_IS_B)                                                                \
+    {                                                                                                \
+      BCN_CELLS(SRC, DST)                                                                            \
+      real acc0 = 0, acc1 = 0;                                                                       \
+      _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
+        const real d0 = DST[0][k] - SRC[0][k], d1 = DST[1][k] - SRC[1][k];                           \
+        acc0 += d0 * d0; acc1 += d1 * d1;                                                            \
+      }                                                                                              \
+      const real pI = wl0 * acc0 + wl1 * acc1;                                                       \
+      real dW0 = DST[0][0] - SRC[0][0], dW1 = DST[1][0] - SRC[1][0];                                 \
+      real dE0 = DST[0][RW - 1] - SRC[0][RW - 1], dE1 = DST[1][RW - 1] - SRC[1][RW - 1];                 \
+      dW0 *= dW0; dW1 *= dW1; dE0 *= dE0; dE1 *= dE1;                                                \
+      const real part = pI + (cW0 * dW0 + cW1 * dW1) + (cE0 * dE0 + cE1 * dE1);                      \
+      const real tot63 = wave_sum_lane63<real>(part);                                                \
+      if (lane == 63) errp[xb * 32 + w] = tot63;                                                     \
+      if (A.conv_plan == 1) {   /* unweighted interior norm (lanes past the top row pair hold zeros) */ \
+        const real totu63 = wave_sum_lane63<real>((acc0 + acc1) + (dW0 + dW1) + (dE0 + dE1));        \
+        if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                             \
+      }                                                                                              \
+      __syncthreads();                                                                               \
+      itp++;                                                                                         \
+      const real eW = errp[xb * 32 + (lane & 15)];                                                   \
+      const real eU = (A.conv_plan == 1) ? errp[xb * 32 + 16 + (lane & 15)] : real(0);               \
+      BCN_HALO_READS                                                                                 \
+      const real err = read_lane(row16_sum<real>(eW), 15);                                           \
+      if (!(err > A.tol)) {                                                                          \
+        if (skip_left > 0) status |= BCN_ST_PLAN;                                                    \
+        finalB = DST_IS_B; break;                                                                    \
+      }                                                                                              \
+      if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; }                       \
+      n = 0;                                                                                         \
+      if (skip_left > 0) {                                                                           \
+        skip_left--;                                                                                 \
+      } else if (A.conv_plan > 0) {                                                                  \
+        const float l2w = __log2f((float)err);                                                       \
+        float l2u = 0;                                                                               \
+        if (A.conv_plan == 1) l2u = __log2f((float)read_lane(row16_sum<real>(eU), 15));              \
+        int j = 0;                                                                                   \
+        if (k_prev >= 0) {                                                                           \
+          const float rg = 1.f / (float)(itp - 1 - k_prev);                                          \
+          if (A.conv_plan == 1) {                                                                    \
+            const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;                       \
+            if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX;   \
+          } else {                                                                                   \
+            const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;                       \
+            int jw = 0;                                                                              \
+            if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX;  \
+            j = jw - 1 - (jw >> 4);                                                                  \
+            j = j > 0 ? j : 0;                                                                       \
+          }                                                                                          \
+        }                                                                                            \
+        j = __builtin_amdgcn_readfirstlane(j);                                                       \
+        l2u_prev = l2u; l2w_prev = l2w; k_prev = itp - 1;                                            \
+        if (A.verify_conv) skip_left = j; else n = j;                                                \
+      }                                                                                              \
     }
     for (;;) {
-      BCN_SWEEP(phA, phB, false)
-      BCN_SWEEP(phB, phA, true)
+      int n;
+      BCN_CHECK(phA, phB, true)
+      if (n == 0) {
+        BCN_CHECK(phB, phA, false)
+        n &= ~1;
+      } else {
+        BCN_FAST(phB, phA)
+        n = (n - 1) & ~1;
+      }
+      if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
+      for (; n > 0; n -= 2) {
+        BCN_FAST(phA, phB)
+        BCN_FAST(phB, phA)
+      }
     }
-#undef BCN_SWEEP
+#undef BCN_CHECK
+#undef BCN_FAST
+#undef BCN_HALO_READS
+#undef BCN_CELLS
 #undef BCN_CELL
     if (finalB) {
 #pragma unroll
@@ -407,6 +453,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
         for (int k = 0; k < RW; k++) phA[a][k] = phB[a][k];
     }
+    hW0 = hW0r; hW1 = hW1r;   // west halo of the final phi (unused by wave 0)
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 
     cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
@@ -529,7 +576,7 @@ __global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_sched(NS2D
   using G = Fast2Geom<NX, NY, R>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words at the end of the `red` scratch row (block_sum uses red[0..NW), the transport sink red[16..17])
-  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) + G::EXCH + 96 + 24);
+  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) + G::EXCH + 128 + 24);
   ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
     fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
   });
@@ -541,6 +588,7 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   const size_t lds = G::lds_elems() * sizeof(real);
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
+  if (const char* e = getenv("BCN_VERIFY_CONV")) c.verify_conv = atoi(e);
   const SchedParams sp = ns2d_sched_params(a);
   const int q = sp.q_set ? sp.q : 20;   // 100x100: 20 timesteps per chunk measured best (37.7 vs 38.2 ms at 10)
   if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * q && a.sched_ctl) {

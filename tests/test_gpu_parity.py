@@ -531,13 +531,22 @@ def test_convergence_plan_never_skips_a_passing_sweep():
             assert np.array_equal(env.sweeps.cpu().numpy()[0], g["itp"][0])
             out.append((env.status.clone(), env.sweeps.clone(), env.get_state().clone()))
             env.close()
+        for p in ([plan] if plan is not None else [1, 2]):     # mixing from rest: solves of up to 2466 sweeps
+            env = V.VecMixing(8, DEV, "f32")
+            env.set_ndt_act(40)
+            env.set_option("verify_conv", verify)
+            env.set_option("conv_plan", p)
+            env.reset()
+            env.step(np.arange(8) % 4)
+            out.append((env.status.clone(), env.sweeps.clone(), env.get_state().clone()))
+            env.close()
         return out
     planned, verified = run(0), run(1)
     for (st_p, sw_p, f_p), (st_v, sw_v, f_v) in zip(planned, verified):
         assert int(st_v.max()) == 0 and int(st_p.max()) == 0          # no BCN_ST_PLAN, no overflow
         assert torch.equal(sw_p, sw_v) and torch.equal(f_p, f_v)
     literal = run(0, plan=0)                                          # every sweep evaluated, as the reference does
-    for i, j in ((0, 0), (1, 1), (2, 1), (3, 2), (4, 2)):
+    for i, j in ((0, 0), (1, 1), (2, 1), (3, 2), (4, 2), (5, 3), (6, 3)):
         assert torch.equal(planned[i][1], literal[j][1]) and torch.equal(planned[i][2], literal[j][2])
 
 
