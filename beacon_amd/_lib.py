@@ -86,6 +86,7 @@ SIGNATURES = {
     "bcn_set_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_variant": (C.c_int, [vp, C.c_int]),
     "bcn_get_counters": (C.c_int, [vp, C.POINTER(C.c_uint64), vp]),
+    "bcn_set_fast_plugin": (C.c_int, [vp, vp, C.c_size_t]),
     "bcn_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "bcn_set_sched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bcn_kernel_name": (C.c_char_p, [vp]),
@@ -118,7 +119,7 @@ def load():
             raise RuntimeError("libbeacon_hip.so is missing or older than its sources and hipcc is not "
                                "available to build it; beacon_amd has no CPU fallback")
         path = _build.build_lib()
-    L = C.CDLL(path)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)   # the on-demand kernel plugins resolve bcn_set_error against it
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res

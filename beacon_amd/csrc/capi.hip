@@ -11,7 +11,8 @@
 
 static thread_local char g_err[512] = "";
 
-void bcn_set_error(const char* fmt, ...) {
+// default visibility: the on-demand kernel plugins (csrc/jit/ns2d_jit.hip) report through the library's error buffer
+__attribute__((visibility("default"))) void bcn_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -131,12 +132,30 @@ struct NS2DEnv : bcn_env_s {
     BCN_HIP(hipStreamSynchronize(s));
     return BCN_OK;
   }
+  typedef int (*plugin_fn)(const void*, int, void*);
+  plugin_fn plugin = nullptr;        // register-resident kernel of a grid that is not built in (bcn_set_fast_plugin)
+  int set_fast_plugin(void* fn, size_t scratch_elems) override {
+    if (!fn) { plugin = nullptr; fast_ok = ns2d_fast_supported<real>(a); variant = fast_ok ? 1 : 0; return BCN_OK; }
+    if (scratch_elems > 0) {
+      DeviceGuard g(device);
+      fscrbuf.release();
+      int rc = fscrbuf.alloc((size_t)batch * scratch_elems * sizeof(real));
+      if (rc) return rc;
+      BCN_HIP(hipMemset(fscrbuf.p, 0, fscrbuf.bytes));
+      a.fscr = static_cast<real*>(fscrbuf.p);
+      a.fscr_stride = scratch_elems;
+    }
+    plugin = reinterpret_cast<plugin_fn>(fn);
+    fast_ok = true; variant = 1; launched = nullptr;
+    return BCN_OK;
+  }
   const char* launched = nullptr;   // name of the kernel the last step dispatched
   const char* kernel_name() const override {
     return launched ? launched : (variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step");
   }
   int launch(hipStream_t s) {
     a.launched = &launched;
+    if (variant == 1 && plugin) return plugin(&a, batch, s);
     if (variant == 1) return ns2d_launch_fast<real>(a, batch, s);
     return ns2d_launch_generic<real>(a, batch, s);
   }
@@ -548,6 +567,10 @@ int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream) {
   if (!h || !buf_host) { bcn_set_error("null handle/buffer"); return BCN_ERR_ARG; }
   DeviceGuard g(h->device);
   return h->get_counters(buf_host, static_cast<hipStream_t>(stream));
+}
+int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_elems) {
+  if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }
+  return h->set_fast_plugin(launch_fn, scratch_elems);
 }
 int bcn_set_option(bcn_env_t h, const char* name, int value) {
   if (!h || !name) { bcn_set_error("null handle/name"); return BCN_ERR_ARG; }

@@ -1,706 +1,9 @@
-// ns2d_fast.hip -- register-resident CDNA4 rayleigh action step (variant 1).
-//
-// One workgroup of NW = NX/R waves per replica runs the whole action step on chip:
-//   * lanes run along y (lane l <-> row j = l+1, NY <= 64), wave w owns the R columns
-//     i = w*R+1 .. w*R+R, so every thread holds R consecutive x-cells of row j in VGPRs;
-//   * p, u*, v*, the Poisson rhs and phi live in registers for the whole step; u, v, T live
-//     in LDS in [i][j] order (lanes consecutive in j: bank-conflict free, also for the
-//     skewed accesses of the transport sweep); HBM is read once on entry, written once on exit;
-//   * Jacobi sweep: x-neighbours are the thread's own registers, y-neighbours come from the
-//     adjacent lanes by DPP wave shifts (whose boundary lanes give the Neumann ghost for
-//     free), only the two strip-edge columns of each wave go through a double-buffered LDS
-//     exchange -- ONE barrier per sweep, which also carries the convergence test: per-wave
-//     DPP-reduced partial sums of the squared increment, combined in a fixed order by every
-//     wave (deterministic sweep counts);
-//   * transport (the reference's in-place sweep, rayleigh.py:468-487): explicit part of all
-//     cells in parallel, then ONE wave walks the nx+ny-1 anti-diagonals with the two
-//     dependent FMAs per cell in registers (west = own previous value, south = DPP from the
-//     lane below), coefficients prefetched from LDS PD diagonals ahead.
-//
-// Semantics are those of ns2d_generic.hip (same citations); tests compare both variants.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "bcn_dpp.h"
-#include "ns2d.h"
-#include "ns2d_device.h"
-#include "ns2d_sched.h"
-
-#ifndef BCN_R128
-#define BCN_R128 16
-#endif
-#ifndef BCN_R50
-#define BCN_R50 5     // columns per lane of the 50x50 kernels
-#endif
-#ifndef BCN_GFD
-#define BCN_GFD 2   // float64 128x64: 1 = u, v, T in global scratch, 2 = u, v in LDS and T in global scratch
-#endif
-#ifndef BCN_PDG
-#define BCN_PDG 4    // deeper (16, 32) costs registers in the out-of-line chain and slows the whole kernel
-#endif
-#ifndef BCN_R128D
-#define BCN_R128D 16   // columns per lane of the float64 128x64 kernel
-#endif
-
+// ns2d_fast.hip -- the register-resident kernels (ns2d_fast_impl.h) instantiated for the grids built into the library:
+// the metric grid 128x64 (float32 / float64), the reference's default 50x50 and its other natural aspect ratios.
+// Every other grid gets its own instantiation at run time (ns2d_jit.hip, beacon_amd/jit.py).
+#include "ns2d_fast_impl.h"
 
 namespace {
-
-using namespace bcn_dpp;
-
-// GF ("global fields", float64 at 128x64: 3 x 68.6 KB do not fit LDS): 1 = u, v, T (with the same pads) live in
-// a per-workgroup global scratch and LDS holds only the exchange buffers; 2 = u, v in LDS without pads (the
-// transport wave clamps its skewed reads instead) and only T, with its pads, in the global scratch.
-template <int NX, int NY, int R, int GF = 0>
-struct FastGeom {
-  static_assert(NX % R == 0, "strip width must divide nx");
-  static_assert(NY <= 64, "lanes run along y");
-  static constexpr int NW = NX / R;
-  static_assert(NW <= 16, "at most 16 waves");
-  static constexpr int NT = NW * 64;
-  static constexpr int SY = NY + 2;
-  static constexpr int SX = NX + 2;
-  static constexpr int SZ = SX * SY + 16;  // +16: lanes >= NY read (never write) past the array
-  static constexpr int PD = GF ? BCN_PDG : 4;   // transport prefetch depth (diagonals); deeper for global fields
-  // LDS map (elements): [ exchange 2*NW*2*64 | errp 64 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
-  // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
-  // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
-  static constexpr int EXCH = 2 * NW * 2 * 64;              // [2 buffers][NW][west edge | east edge][64]
-  static constexpr int MISC = EXCH + 160 + 16;              // + 16: scheduler words (ns2d_fast_sched)
-  static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
-  static constexpr int BACK = (NY + PD + 1) * SY;
-  static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
-  static constexpr int MISCA = (MISC + 15) / 16 * 16;
-  static constexpr size_t lds_elems() {
-    return GF == 1 ? (size_t)MISCA : GF == 2 ? (size_t)MISCA + 2 * (size_t)SZ : (size_t)FRONT + 3 * (size_t)SZ + BACK;
-  }
-  static constexpr size_t scratch_elems() {
-    return GF == 1 ? (size_t)FRONTG + 3 * (size_t)SZ + BACK : GF == 2 ? (size_t)FRONTG + SZ + BACK : 0;
-  }
-};
-
-// Ordered part of the transport step, run by ONE wave (kept out of line: its unrolled,
-// software-pipelined loops would otherwise inflate the register pressure of the whole kernel).
-template <typename real, int NX, int NY, int R, int GF>
-__device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* Ul, const real* Vl, real* dummy,
-                                                          real c0x, real c1x, real c0y, real c1y) {
-  using G = FastGeom<NX, NY, R, GF>;
-  constexpr int SY = G::SY, PD = G::PD;
-  const int lane = threadIdx.x & 63;
-  const int j = lane + 1;
-  const bool active = lane < NY;
-      constexpr int NSTEP = NX + NY - 1;
-      // At step t this lane works on cell (i, j) = (t - lane + 1, lane + 1), index cb + t*SY.  The
-      // element just below it, index - 1, is the south ghost T[i][0] for lane 0 (never written
-      // here, so it can be prefetched); the other lanes take their south value from the lane
-      // below by DPP and ignore it.  Reads are unmasked (see the LDS map), only writes are.
-      const int cb = (1 - lane) * SY + j;
-      real* Tb = Tl + cb;
-      // u, v without pads (GF == 2): lanes outside the domain read a clamped index (their values are masked)
-      auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ul[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ul[x]; };
-      auto ldv = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Vl[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Vl[x]; };
-      real ra[PD], ru[PD], rv[PD], rg[PD];
-#pragma unroll
-      for (int q = 0; q < PD; q++) { ra[q] = Tb[q * SY]; ru[q] = ldu(q); rv[q] = ldv(q); rg[q] = Tb[q * SY - 1]; }
-      real tp = Tl[0 * SY + j];                        // west ghost
-      // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
-#define BCN_CHAIN(T0, T1, MASK)                                                             \
-      for (int t0 = (T0); t0 < (T1); t0 += PD) {                                            \
-        _Pragma("unroll") for (int q = 0; q < PD; q++) {                                    \
-          const int t = t0 + q;                                                             \
-          const real s = from_below(rg[q], tp);                                             \
-          const real aw = c0x + c1x * ru[q], as = c0y + c1y * rv[q];                        \
-          const real tn = ra[q] + aw * tp + as * s;                                         \
-          if (MASK == 0) {                                                                  \
-            tp = tn;                                                                        \
-            Tb[t * SY] = tn;                                                                \
-          } else {                                                                          \
-            const bool ok = active && (MASK != 2 ? (lane <= t) : true) &&                   \
-                            (MASK != 1 ? (lane > t - NX && t < NSTEP) : true);              \
-            tp = ok ? tn : tp;                                                              \
-            real* dst = ok ? Tb + t * SY : dummy;                                           \
-            *dst = tn;                                                                      \
-          }                                                                                 \
-          ra[q] = Tb[(t + PD) * SY];                                                        \
-          ru[q] = ldu(t + PD);                                                              \
-          rv[q] = ldv(t + PD);                                                              \
-          rg[q] = Tb[(t + PD) * SY - 1];                                                    \
-        }                                                                                   \
-      }
-      // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of PD
-      constexpr int TA = ((NY - 1 + PD - 1) / PD) * PD;      // first steady step (rounded up)
-      constexpr int TB = (NX / PD) * PD;                      // end of the steady phase (rounded down)
-      if constexpr (TA <= TB) {
-        BCN_CHAIN(0, TA, 1)
-        if (NY == 64) { BCN_CHAIN(TA, TB, 0) } else { BCN_CHAIN(TA, TB, 1) }
-        BCN_CHAIN(TB, NSTEP, 2)
-      } else {                                               // (nearly) square grid: no steady phase
-        constexpr int TL = ((NY - 1) / PD) * PD, TH = ((NX + PD - 1) / PD) * PD;
-        BCN_CHAIN(0, TL, 1)
-        BCN_CHAIN(TL, TH, 3)
-        BCN_CHAIN(TH, NSTEP, 2)
-      }
-#undef BCN_CHAIN
-    }
-
-// One unit of work: timesteps [it_begin, it_end) of replica b (state HBM -> chip -> HBM).
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
-                                          const bool first_chunk, const bool last_chunk, char* smem) {
-  using G = FastGeom<NX, NY, R, GF>;
-  constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
-  real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
-  real* errp = exch + G::EXCH;                 // [2][2][16]: reference norm / unweighted norm partials
-  real* sact = errp + 64;                      // [64]
-  real* red = sact + 64;                       // [32]
-  real* gscr = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride + G::FRONTG : nullptr;
-  real* Ul = GF == 1 ? gscr : GF == 2 ? exch + G::MISCA : exch + G::FRONT;
-  real* Vl = Ul + SZ;
-  real* Tl = GF == 2 ? gscr : Vl + SZ;
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int j = lane + 1;
-  const bool active = lane < NY;
-  const int i0 = w * R + 1;
-  const size_t off = (size_t)b * A.ncell;
-  real* __restrict__ gu = A.u + off;
-  real* __restrict__ gv = A.v + off;
-  real* __restrict__ gp = A.p + off;
-  real* __restrict__ gS = A.S + off;
-  auto ex = [&](int buf, int wave, int which) -> real* { return exch + ((buf * NW + wave) * 2 + which) * 64; };
-
-  // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
-  for (int c = tid; c < SX * SY; c += NT) {
-    const int jj = c / SX, ii = c - jj * SX;
-    Ul[ii * SY + jj] = gu[c];
-    Vl[ii * SY + jj] = gv[c];
-    Tl[ii * SY + jj] = gS[c];
-  }
-  for (int c = SX * SY + tid; c < SZ; c += NT) { Ul[c] = 0; Vl[c] = 0; Tl[c] = 0; }
-  if (tid < 64) errp[tid] = 0;
-  real p[R];
-#pragma unroll
-  for (int k = 0; k < R; k++) p[k] = active ? gp[j * SX + i0 + k] : real(0);
-
-  // ---- action conditioning (rayleigh.py:162-171); later chunks reuse the conditioned vector ----
-  if (!first_chunk) {
-    if (tid < A.n_sgts) sact[tid] = A.a_last[(size_t)b * A.n_sgts + tid];
-  } else {
-    const int n = A.n_sgts;
-    const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
-    real mean = 0;
-    for (int k = 0; k < n; k++) mean += src[k];
-    mean /= (real)n;
-    real m = 1;
-    for (int k = 0; k < n; k++) {
-      real t = bcn_abs(src[k] - mean) / A.C;
-      m = t > m ? t : m;
-    }
-    real mine = (tid < n) ? (src[tid] - mean) / m : real(0);
-    __syncthreads();
-    if (tid < n) {
-      sact[tid] = mine;
-      A.a_last[(size_t)b * n + tid] = mine;
-      if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
-    }
-  }
-  __syncthreads();
-
-  const real dt = A.dt, rdx = A.rdx, rdy = A.rdy, rdx2 = A.rdx2, rdy2 = A.rdy2;
-  const real cx = A.cx, cy = A.cy;
-  // err weight of this lane's row: ghosts copy their interior neighbour (rayleigh.py:432-449)
-  const real wl = active ? real(1) + (j == 1 ? 1 : 0) + ((j == NY && KIND == 0) ? 1 : 0) : real(0);
-  const real fW = (active && w == 0) ? real(1) : real(0);
-  const real fE = (active && w == NW - 1) ? real(1) : real(0);
-  const real cW = wl + fW, cE = wl + fE;   // weights of the strip's first / last column (ghost columns included)
-  // coefficient of the lane's own value from the y-ghosts (bottom: always Neumann; top: rayleigh)
-  const real cBy = cy * (real)((lane == 0 ? 1 : 0) + ((lane == NY - 1 && KIND == 0) ? 1 : 0));
-  const real actf = active ? real(1) : real(0);
-
-  int status = 0;
-  int xb = 0;
-#ifdef BCN_STAMP
-  const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long tl = kt0;
-#define BCN_PH(x) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); seg[x] += t__ - tl; tl = t__; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define BCN_PH(x)
-#endif
-  if (!first_chunk) status = A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
-  const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
-  unsigned long long cyc_j = 0;
-  for (int it = it_begin; it < it_end && status == 0; it++) {
-    // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
-    for (int jj = 1 + tid; jj <= NY; jj += NT) {
-      Ul[1 * SY + jj] = 0;
-      Ul[(NX + 1) * SY + jj] = 0;
-      if (jj >= 2) {
-        Vl[0 * SY + jj] = -Vl[1 * SY + jj];
-        Vl[(NX + 1) * SY + jj] = -Vl[NX * SY + jj];
-      }
-      Tl[0 * SY + jj] = Tl[1 * SY + jj];
-      Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
-    }
-    for (int ii = 1 + tid; ii <= NX + 1; ii += NT) {
-      const bool wall = (ii == 1) || (ii == NX + 1);
-      const real utop = wall ? real(0) : Ul[ii * SY + NY];
-      const real ubot = wall ? real(0) : Ul[ii * SY + 1];
-      Ul[ii * SY + NY + 1] = -utop;
-      Ul[ii * SY + 0] = -ubot;
-      if (ii <= NX) {
-        Vl[ii * SY + NY + 1] = 0;
-        Vl[ii * SY + 1] = 0;
-        Tl[ii * SY + NY + 1] = 2 * A.Tc - Tl[ii * SY + NY];
-        const int k = (ii - 1) / A.nx_sgts;
-        if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
-      }
-    }
-    ex(xb, w, 1)[lane] = p[R - 1];
-    __syncthreads();
-    BCN_PH(0)
-
-    // ---- predictor (rayleigh.py:370-407) -> u*, v* in registers -----------------------------
-    real us[R], vs[R];
-    {
-      const real pWh = (w > 0) ? ex(xb, w - 1, 1)[lane] : real(0);
-      xb ^= 1;
-      // float64 (GF) and wide strips: in chunks of CH columns, so that the seven neighbour arrays fit the register file
-      constexpr bool WIDE = (R > 16) || (R > 12 && NW > 8);   // more live values than the wave's register budget
-      constexpr int CH = GF ? 4 : (!WIDE ? R : (R % 5 == 0 ? 5 : (R % 4 == 0 ? 4 : R)));
-      static_assert(R % CH == 0, "chunked predictor");
-#pragma unroll
-      for (int c0 = 0; c0 < R; c0 += CH) {
-        if (CH != R) __builtin_amdgcn_sched_barrier(0);   // finish one chunk before loading the next
-        real ur[CH + 2], uS[CH + 1], uN[CH], vr[CH + 2], vN[CH + 1], vS[CH], Tc[CH];
-        const int ic = i0 + c0;
-#pragma unroll
-        for (int k = 0; k < CH + 2; k++) { ur[k] = Ul[(ic - 1 + k) * SY + j]; vr[k] = Vl[(ic - 1 + k) * SY + j]; }
-#pragma unroll
-        for (int k = 0; k < CH + 1; k++) { uS[k] = Ul[(ic + k) * SY + j - 1]; vN[k] = Vl[(ic - 1 + k) * SY + j + 1]; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) { uN[k] = Ul[(ic + k) * SY + j + 1]; vS[k] = Vl[(ic + k) * SY + j - 1]; Tc[k] = Tl[(ic + k) * SY + j]; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const int i = ic + k, kk = c0 + k;
-          const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
-          const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
-          const real pc = p[kk];
-          const real pW = (kk > 0) ? p[kk > 0 ? kk - 1 : 0] : pWh;
-          const real pS = from_below(pc, pc);
-          {
-            real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
-            real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
-            real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
-            real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
-            real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
-            real pres = (pc - pW) * rdx;
-            us[kk] = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
-          }
-          {
-            real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
-            real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
-            real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
-            real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
-            real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
-            real pres = (pc - pS) * rdy;
-            const real buoy = (KIND == 0) ? Tc[k] : real(0);
-            vs[kk] = (j >= 2 && active) ? vc + dt * (diff - conv - pres + buoy) : real(0);
-          }
-        }
-      }
-    }
-    ex(xb, w, 0)[lane] = us[0];
-    __syncthreads();
-
-    // ---- Poisson rhs (rayleigh.py:424-426) ---------------------------------------------------
-    real nb[R];   // minus the scaled rhs
-    {
-      const real usE = (w < NW - 1) ? ex(xb, w + 1, 0)[lane] : real(0);   // u*[nx+1,.] = 0
-      xb ^= 1;
-#pragma unroll
-      for (int k = 0; k < R; k++) {
-        const real ue = (k < R - 1) ? us[k < R - 1 ? k + 1 : 0] : usE;
-        const real vn = from_above(real(0), vs[k]);                        // v*[., ny+1] = 0 (lanes >= NY hold 0)
-        nb[k] = active ? -A.cb * ((ue - us[k]) * rdx + (vn - vs[k]) * rdy) : real(0);
-      }
-    }
-
-    BCN_PH(1)
-    const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
-    // ---- Jacobi sweeps (rayleigh.py:419-454): one barrier per sweep --------------------------
-    // phi ping-pongs between two register arrays (no copies).  Behind the barrier of a sweep the LDS reads of the
-    // strip-edge halos are issued first and the R-2 interior cells of the NEXT sweep are computed while they are in
-    // flight; the two edge cells follow and go to the exchange buffer at once.
-    //
-    // Which sweeps evaluate the residual.  The reference evaluates err_k = sum((phi_k - phi_{k-1})^2) over the whole
-    // array after EVERY sweep and stops at the first k with err_k <= tol (rayleigh.py:448-454).  A sweep is
-    // d_{k+1} = J d_k for the increments d_k, with J = (Adj + G) / 4 symmetric (Adj: neighbour matrix of the interior
-    // cells, G: diagonal count of mirrored ghost sides; a Dirichlet-zero ghost drops out), so the UNWEIGHTED interior
-    // norm a_k = |d_k|^2 = sum_i lambda_i^{2k} c_i^2 is log-convex in k: its per-sweep decay factor a_{k+1}/a_k never
-    // decreases.  Hence, from two evaluated sweeps kp < k, rho = (a_k / a_kp)^(1/(k-kp)) is a lower bound of every
-    // later factor, and err_{k+i} >= a_{k+i} >= a_k rho^i (the reference's norm counts the ghost copies on top of the
-    // interior: err = d'(I+G)d >= a).  While a_k rho^i > 1.02 tol the test cannot pass, and those sweeps run WITHOUT
-    // the residual (5 instead of 7 instructions per cell, no wave reduction, no partials through LDS).
-    // A.conv_plan: 0 = evaluate every sweep (the reference, literally); 1 = skip only what the bound above proves
-    // (exact stop sweep: the float64 default); 2 = extrapolate the reference norm itself instead, whose decay factor is
-    // observed -- not proven: I+G does not commute with J -- never to decrease either (10 000 sweeps of oracle traces,
-    // scripts/plan_sim.py), ending the skip 1 + 1/16 of its length early (the float32 default: the evaluations drop
-    // from ~28 % to ~9 % of the sweeps).  A.verify_conv evaluates every sweep anyway and raises
-    // BCN_ST_PLAN if a sweep the plan would have skipped passes the test (tests/test_gpu_parity.py).
-    auto cell = [&](real c, real e, real wv, real nbk) -> real {
-      const real q = cBy * c + nbk;                       // Neumann ghosts in y copy the cell itself
-      real ph;
-      if (EQ) {
-        real sum = e + wv;
-        sum = add_above_below(sum, c);                    // + north (lane+1) + south (lane-1); 0 outside the wave
-        ph = cx * sum + q;
-      } else {
-        const real ns = dpp<0x130, 0xf, 0xf, true>(real(0), c) + dpp<0x138, 0xf, 0xf, true>(real(0), c);
-        ph = cx * (e + wv) + (cy * ns + q);
-      }
-      if (NY < 64) ph *= actf;                            // lanes past the top row stay 0
-      return ph;
-    };
-    const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
-    real hW = 0, hE = 0;            // halos of the array the last sweep read
-    real hWr = 0, hEr = 0;          // halos of the array the last sweep wrote (LDS reads issued behind its barrier)
-    int itp = 0;
-#ifdef BCN_STAMP
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-#endif
-    real phA[R], phB[R];
-#pragma unroll
-    for (int k = 0; k < R; k++) phA[k] = 0;
-    bool finalB = false;
-    int k_prev = -1;                // index of the planned evaluation before the last one, log2 of its two norms
-    float l2u_prev = 0, l2w_prev = 0;
-    int skip_left = 0;              // verify_conv: sweeps the plan would still skip
-#ifdef BCN_DBG_NCHK
-    int nchk = 0;
-#define BCN_NCHK_INC nchk++;
-#else
-#define BCN_NCHK_INC
-#endif
-    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
-    constexpr int JMAX = 256;
-    // all cells of one sweep; the two strip-edge cells come last (their halos were requested behind the previous
-    // barrier) and go to the exchange buffer at once, in front of whatever else the sweep still has to do
-#define BCN_CELLS(SRC, DST)                                                                  \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) DST[k] = cell(SRC[k], SRC[k + 1], SRC[k - 1], nb[k]); \
-      /* keep the halo-dependent part behind the interior cells: hipcc otherwise sometimes hoists the edge cells \
-         (and their s_waitcnt on the LDS reads) in front of them: +170 cycles per sweep */   \
-      __builtin_amdgcn_sched_barrier(0);                                                     \
-      hW = (w > 0) ? hWr : SRC[0];                                                           \
-      hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                  \
-      const real p0 = cell(SRC[0], SRC[1], hW, nb[0]);                                       \
-      const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
-      DST[0] = p0;                                                                           \
-      DST[R - 1] = pl;                                                                       \
-      ex(xb, w, 0)[lane] = p0;                                                               \
-      ex(xb, w, 1)[lane] = pl;
-#define BCN_SWEEP_END                                                                        \
-      __syncthreads();                                                                       \
-      itp++;                                                                                 \
-      hWr = ex(xb, wm, 1)[lane];                                                             \
-      hEr = ex(xb, wp, 0)[lane];                                                             \
-      xb ^= 1;
-    // a sweep that does not evaluate the residual
-#define BCN_FAST(SRC, DST) { BCN_CELLS(SRC, DST) BCN_SWEEP_END }
-    // a sweep that does (the same arithmetic, in the same order, as when it was fused into the cells), evaluated right
-    // behind its barrier; sets `n`: the number of following sweeps that cannot pass the test
-#define BCN_CHECK(SRC, DST, DST_IS_B)                                                        \
-    {                                                                                        \
-      BCN_CELLS(SRC, DST)                                                                    \
-      BCN_NCHK_INC                                                                           \
-      real acc = 0;                                                                          \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) { const real d = DST[k] - SRC[k]; acc += d * d; } \
-      const real pI = wl * acc;                                                              \
-      const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
-      const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
-      const real tot63 = wave_sum_lane63<real>(part);                                        \
-      if (lane == 63) errp[xb * 32 + w] = tot63;                                             \
-      if (A.conv_plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
-        const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + dl * dl);                  \
-        if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                     \
-      }                                                                                      \
-      real eB[NW], eU[NW];                                                                   \
-      __syncthreads();                                                                       \
-      itp++;                                                                                 \
-      _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 32 + q];              \
-      if (A.conv_plan == 1) { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = errp[xb * 32 + 16 + q]; } \
-      else { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = 0; }                     \
-      hWr = ex(xb, wm, 1)[lane];                                                             \
-      hEr = ex(xb, wp, 0)[lane];                                                             \
-      xb ^= 1;                                                                               \
-      /* every lane sums the NW partials it read by broadcast, in a fixed order: uniform */  \
-      _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                   \
-        _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st];     \
-      const real err = read_lane(eB[0], 0);                                                  \
-      if (!(err > A.tol)) {                                                                  \
-        if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
-        finalB = DST_IS_B; break;                                                            \
-      }                                                                                      \
-      if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; }               \
-      n = 0;                                                                                 \
-      if (skip_left > 0) {                                                                   \
-        skip_left--;                                                                         \
-      } else if (A.conv_plan > 0) {   /* plan the next evaluation (see above) */             \
-        float l2u = 0;                                                                       \
-        if (A.conv_plan == 1) {                                                              \
-          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                               \
-            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eU[q] += eU[q + st]; \
-          l2u = __log2f((float)read_lane(eU[0], 0));                                         \
-        }                                                                                    \
-        const float l2w = __log2f((float)err);                                               \
-        int j = 0;                                                                           \
-        if (k_prev >= 0) {                                                                   \
-          const float rg = 1.f / (float)(itp - 1 - k_prev);                                  \
-          if (A.conv_plan == 1) {                                                            \
-            const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;               \
-            if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
-          } else {                                                                           \
-            const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;               \
-            int jw = 0;                                                                      \
-            if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
-            j = jw - 1 - (jw >> 4);                                                          \
-            j = j > 0 ? j : 0;                                                               \
-          }                                                                                  \
-        }                                                                                    \
-        j = __builtin_amdgcn_readfirstlane(j);                                               \
-        l2u_prev = l2u; l2w_prev = l2w; k_prev = itp - 1;                                    \
-        if (A.verify_conv) skip_left = j; else n = j;                                        \
-      }                                                                                      \
-    }
-    for (;;) {
-      int n;
-      BCN_CHECK(phA, phB, true)
-      if (n == 0) {
-        BCN_CHECK(phB, phA, false)
-        n &= ~1;
-      } else {
-        BCN_FAST(phB, phA)
-        n = (n - 1) & ~1;
-      }
-      if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
-      for (; n > 0; n -= 2) {
-        BCN_FAST(phA, phB)
-        BCN_FAST(phB, phA)
-      }
-    }
-#undef BCN_CHECK
-#undef BCN_FAST
-#undef BCN_SWEEP_END
-#undef BCN_CELLS
-    if (finalB) {
-#pragma unroll
-      for (int k = 0; k < R; k++) phA[k] = phB[k];
-    }
-    hW = hWr;   // west halo of the final phi (read behind the last barrier; unused by wave 0)
-#ifdef BCN_STAMP   // diagnostic build only: cycles per sweep in the high half of the sweep count
-    {
-      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-      const int cps = (int)((st1 - st0) / (unsigned long long)(itp > 0 ? itp : 1));
-      if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp | (cps << 16);
-    }
-#elif defined(BCN_DBG_NCHK)   // diagnostic build only: residual evaluations in the high half of the sweep count
-    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp | (nchk << 16);
-#else
-    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
-#endif
-
-    cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
-    BCN_PH(2)
-    // ---- p += phi (rayleigh.py:219), corrector (rayleigh.py:460-464) -> LDS u, v --------------
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-      const int i = i0 + k;
-      const real ph = phA[k];
-      const real pw = (k > 0) ? phA[k > 0 ? k - 1 : 0] : hW;
-      const real ps = from_below(ph, ph);
-      p[k] += ph;
-      if (active) {
-        if (i >= 2) Ul[i * SY + j] = us[k] - dt * (ph - pw) * rdx;
-        if (j >= 2) Vl[i * SY + j] = vs[k] - dt * (ph - ps) * rdy;
-      }
-    }
-    __syncthreads();
-
-    BCN_PH(3)
-    // ---- transport, explicit part of every cell (rayleigh.py:468-487) ------------------------
-    {
-      real Ac[R];
-#pragma unroll
-      for (int k = 0; k < R; k++) {
-        const int c = (i0 + k) * SY + j;
-        const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
-        const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
-        const real expl = A.ksc * ((TE - 2 * T0) * rdx2 + (TN - 2 * T0) * rdy2) -
-                          (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
-                          (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
-        Ac[k] = T0 + dt * expl;
-      }
-      __syncthreads();   // every read of the old T is done
-      if (active) {
-#pragma unroll
-        for (int k = 0; k < R; k++) Tl[(i0 + k) * SY + j] = Ac[k];
-      }
-    }
-    __syncthreads();
-
-    BCN_PH(4)
-    // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
-    if (w == 0) {
-      transport_chain<real, NX, NY, R, GF>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
-                                       dt * A.ksc * rdy2, real(0.5) * dt * rdy);
-    }
-    __syncthreads();
-    BCN_PH(5)
-  }
-
-  // ---- store: LDS [i][j] -> HBM [j][i]; p and its ghosts -------------------------------------
-  for (int c = tid; c < SX * SY; c += NT) {
-    const int jj = c / SX, ii = c - jj * SX;
-    gu[c] = Ul[ii * SY + jj];
-    gv[c] = Vl[ii * SY + jj];
-    gS[c] = Tl[ii * SY + jj];
-  }
-  if (active) {
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-      const int i = i0 + k, c = j * SX + i;
-      // a p ghost receives the same increments as its interior neighbour (phi ghosts copy it)
-      const real dp = p[k] - gp[c];
-      if (i == 1) gp[c - 1] += dp;
-      if (i == NX) gp[c + 1] += dp;
-      if (j == 1) gp[c - SX] += dp;
-      if (j == NY && KIND == 0) gp[c + SX] += dp;
-      gp[c] = p[k];
-    }
-  }
-  __syncthreads();
-#ifdef BCN_STAMP   // diagnostic build only: shader clock in MHz (s_memrealtime ticks at 100 MHz)
-  {
-    const unsigned long long kt1 = __builtin_amdgcn_s_memtime(), kr1 = __builtin_amdgcn_s_memrealtime();
-    status = (int)((kt1 - kt0) * 100ull / (kr1 - kr0 + 1));
-    if (tid == 0 && A.actions_norm)
-      for (int q = 0; q < 6; q++) A.actions_norm[(size_t)b * A.n_sgts + q] = (real)seg[q] / (real)(it_end - it_begin);
-
-  }
-#endif
-  if (last_chunk) {
-    ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
-  } else if (tid == 0) {
-    A.status[b] = status;
-  }
-  if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
-    A.cyc[2 * (size_t)b] += cyc_j;
-    A.cyc[2 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
-  }
-}
-
-// plain launch: one workgroup per replica, timesteps [A.it_begin, A.it_end)
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_step(NS2DArgs<real> A) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
-  if (A.mask && !A.mask[b]) return;
-  fast_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, A.it_begin, A.it_end, A.first_chunk != 0, A.last_chunk != 0, smem);
-}
-
-// ---- ticketed chunk scheduler (ns2d_sched.h) ---------------------------------------------------
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__global__ __launch_bounds__((NX / R) * 64) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // two words behind fast_unit's scalars (no static __shared__ in front of the dynamic region)
-  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
-                                                          FastGeom<NX, NY, R, GF>::EXCH + 160);
-  ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
-    fast_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, it0, it1, first, last, smem);
-  });
-}
-
-// ---- LPT ordering between the two launches of one step ---------------------------------------
-// A replica's Jacobi work varies ~10x across a batch (20..240 sweeps per timestep) and each
-// replica is a serial chain on one CU, so with ~2 replicas per CU the step time is set by
-// which CU happens to pick up a long replica late.  The work of the first Q timesteps
-// predicts the rest (r ~ 0.8), so the step runs as [0,Q) in index order, then the remaining
-// timesteps with replicas dispatched longest-first.
-__global__ __launch_bounds__(1024) void ns2d_rank_by_work(const int32_t* sweeps, int ndt, int q, int batch,
-                                                          int32_t* order, const uint8_t* mask) {
-  __shared__ int key[2048];
-  for (int b = threadIdx.x; b < batch; b += blockDim.x) {
-    int s = 0;
-    if (!mask || mask[b])
-      for (int t = 0; t < q; t++) s += sweeps[(size_t)b * ndt + t];
-    key[b] = s;
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < batch; b += blockDim.x) {
-    const int mine = key[b];
-    int rank = 0;
-    for (int o = 0; o < batch; o++) rank += (key[o] > mine || (key[o] == mine && o < b)) ? 1 : 0;
-    order[rank] = b;
-  }
-}
-
-template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
-  using G = FastGeom<NX, NY, R, GF>;
-  if (GF && (!a.fscr || a.fscr_stride < G::scratch_elems())) { bcn_set_error("fast path: field scratch missing"); return BCN_ERR_UNSUPPORTED; }
-  const size_t lds = G::lds_elems() * sizeof(real);
-  auto k = ns2d_fast_step<real, NX, NY, R, KIND, EQ, GF>;
-  static unsigned long long attr_set = 0;
-  if (ns2d_first_on_device(attr_set)) {
-    BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  NS2DArgs<real> c = a;
-  if (!c.sweeps) c.sweeps = c.sweeps_int;
-  if (const char* e = getenv("BCN_VERIFY_CONV")) c.verify_conv = atoi(e);
-  const SchedParams sp = ns2d_sched_params(a);
-  const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
-  if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
-    auto ks = ns2d_fast_sched<real, NX, NY, R, KIND, EQ, GF>;
-    static unsigned long long attr_set2 = 0;
-    if (ns2d_first_on_device(attr_set2)) {
-      BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    const int nchunk = a.ndt_act / SQ;
-    c.sched_q = SQ; c.order = nullptr; c.first_chunk = 1; c.last_chunk = 1; c.it_begin = 0; c.it_end = a.ndt_act;
-    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
-    hipLaunchKernelGGL(ks, dim3(sched_grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
-    BCN_HIP(hipGetLastError());
-    if (a.launched) *a.launched = "ns2d_fast_sched";
-    return BCN_OK;
-  }
-  // split only when replicas outnumber the CUs (otherwise every replica starts at once and
-  // the order cannot matter); BCN_LPT_MIN_BATCH / bcn_set_sched override the threshold (tests)
-  const int min_batch = sp.lpt_min_batch;
-  constexpr int Q = 10;
-  const bool split = mode >= 1 && batch >= min_batch && batch <= 2048 && a.ndt_act >= 4 * Q;
-  c.first_chunk = 1; c.order = nullptr; c.it_begin = 0;
-  if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
-  if (!split) {
-    c.it_end = a.ndt_act; c.last_chunk = 1;
-    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
-  } else {
-    c.it_end = Q; c.last_chunk = 0;
-    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
-    hipLaunchKernelGGL(ns2d_rank_by_work, dim3(1), dim3(1024), 0, s, c.sweeps, a.ndt_act, Q, batch, c.order_out, c.mask);
-    c.first_chunk = 0; c.last_chunk = 1; c.it_begin = Q; c.it_end = a.ndt_act; c.order = c.order_out;
-    hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
-  }
-  BCN_HIP(hipGetLastError());
-  if (a.launched) *a.launched = "ns2d_fast_step";
-  return BCN_OK;
-}
-
-template <typename real, int NX, int NY, int R, int KIND, int GF = 0>
-int launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
-  // dx == dy (every reference configuration): one multiply per cell instead of two
-  if (a.cx == a.cy) return launch_fast_eq<real, NX, NY, R, KIND, true, GF>(a, batch, s);
-  return launch_fast_eq<real, NX, NY, R, KIND, false, GF>(a, batch, s);
-}
 
 template <typename real>
 int fast_config(const NS2DArgs<real>& a) {

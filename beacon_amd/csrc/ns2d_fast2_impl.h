@@ -1,0 +1,625 @@
+// ns2d_fast2_impl.h -- register-resident action step for grids with 64 < ny <= 128, two rows per lane: kernel templates.
+// Instantiated by ns2d_fast2.hip (100x100: mixing's default grid, rayleigh at L = H = 2) and by ns2d_jit.hip (any other grid).
+//
+// Same construction as ns2d_fast.hip, with TWO rows per lane: lane l holds rows j = 2l+1 and 2l+2
+// of the columns i = w*R+1 .. owned by wave w (R columns; the last wave takes the remainder RL, its
+// code is a second instantiation of the same body selected by a wave-uniform branch, so 100 columns
+// run as 7 x 13 + 9 on 8 waves = 512 threads = 2 waves per SIMD with 256 VGPRs each).  Consequences:
+//   * a cell has ONE cross-lane y-neighbour (row 2l+1 looks down to lane l-1's upper row, row 2l+2
+//     looks up to lane l+1's lower row), the other one is the thread's own register: one DPP
+//     shift per cell instead of two;
+//   * the lanes above the last row pair are kept at phi = 0, which IS mixing's top Dirichlet
+//     ghost (mixing.py:450-451); a Neumann top (rayleigh) is a per-lane coefficient of the
+//     centre value, as is the Neumann bottom;
+//   * u*, v* are stored in place of u, v in LDS after the predictor (u, v are dead until the
+//     corrector rewrites them), so the Jacobi loop keeps p, rhs and the phi ping-pong in VGPRs:
+//     4 x 2R registers;
+//   * transport: ONE wave walks the skewed wavefront "lane l works on column t - l" with both of
+//     its rows per step; the west values stay in registers, the south value of the lower row comes
+//     from the lane below by DPP (transport_chain2).
+// Semantics and citations: ns2d_generic.hip.  Plain launch, one workgroup per replica.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "bcn_dpp.h"
+#include "ns2d.h"
+#include "ns2d_device.h"
+#include "ns2d_sched.h"
+
+namespace {
+
+using namespace bcn_dpp;
+
+template <int NX, int NY, int R>
+struct Fast2Geom {
+  static_assert(NY % 2 == 0 && NY <= 128, "two rows per lane");
+  static constexpr int NW = (NX + R - 1) / R;
+  static constexpr int RL = NX - (NW - 1) * R;   // columns of the last wave
+  static_assert(NW <= 16 && RL >= 3 && RL <= R, "at most 16 waves, at least 3 columns each");
+  static constexpr int NT = NW * 64;
+  static constexpr int LH = NY / 2;        // active lanes
+  static constexpr int SY = NY + 2;
+  static constexpr int SX = NX + 2;
+  static constexpr int SZ = SX * SY;
+  // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 64 | sact 64 | red 32 | U V S
+  static constexpr int EXCH = 2 * NW * 4 * 64;
+  static constexpr size_t lds_elems() { return (size_t)EXCH + 160 + 3 * (size_t)SZ; }
+};
+
+// Ordered part of the transport step by ONE wave (out of line, see ns2d_fast.hip).  At step t lane l
+// works on column i = t - l + 1, rows 2l+1 and 2l+2: S' = A + aW S'(i-1,j) + aS S'(i,j-1) with the
+// west values in registers, the south value of the lower row from the lane below (its upper row of
+// the previous step) and the explicit part A, u, v prefetched PD steps ahead from LDS.  Lanes outside
+// the domain compute on clamped addresses and write to `dummy`.
+template <typename real, int NX, int NY>
+__device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real* Ul, const real* Vl, real* dummy,
+                                                           real c0x, real c1x, real c0y, real c1y) {
+  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = NY / 2, PD = 4;
+  constexpr int NSTEP = NX + LH - 1;
+  const int lane = threadIdx.x & 63;
+  const bool active = lane < LH;
+  const int la = active ? lane : LH - 1;
+  const int cb = (1 - la) * SY + 2 * la + 1;     // index of (i, 2l+1) at step t: cb + t*SY
+  auto at = [&](int t) { int x = cb + t * SY; x = x < 1 ? 1 : x; return x > SZ - 2 ? SZ - 2 : x; };
+  real a0[PD], a1[PD], u0[PD], u1[PD], v0[PD], v1[PD], g[PD];
+#pragma unroll
+  for (int q = 0; q < PD; q++) {
+    const int x = at(q);
+    a0[q] = Tl[x]; a1[q] = Tl[x + 1]; g[q] = Tl[x - 1];
+    u0[q] = Ul[x]; u1[q] = Ul[x + 1];
+    v0[q] = Vl[x]; v1[q] = Vl[x + 1];
+  }
+  real tp0 = Tl[2 * la + 1], tp1 = Tl[2 * la + 2];   // west ghosts (column 0)
+  for (int t0 = 0; t0 < NSTEP; t0 += PD) {
+#pragma unroll
+    for (int q = 0; q < PD; q++) {
+      const int t = t0 + q;
+      const real s = from_below(g[q], tp1);          // lane 0: the south ghost T[i][0]
+      const real aw0 = c0x + c1x * u0[q], as0 = c0y + c1y * v0[q];
+      const real aw1 = c0x + c1x * u1[q], as1 = c0y + c1y * v1[q];
+      const real tn0 = a0[q] + aw0 * tp0 + as0 * s;
+      const real tn1 = a1[q] + aw1 * tp1 + as1 * tn0;
+      const bool ok = active && lane <= t && lane > t - NX;
+      tp0 = ok ? tn0 : tp0;
+      tp1 = ok ? tn1 : tp1;
+      real* dst = ok ? Tl + (cb + t * SY) : dummy;
+      dst[0] = tn0;
+      dst[1] = tn1;
+      const int x = at(t + PD);
+      a0[q] = Tl[x]; a1[q] = Tl[x + 1]; g[q] = Tl[x - 1];
+      u0[q] = Ul[x]; u1[q] = Ul[x + 1];
+      v0[q] = Vl[x]; v1[q] = Vl[x + 1];
+    }
+  }
+}
+
+template <typename real, int NX, int NY, int R, int RW, int KIND, bool EQ>
+__device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, const int w, const int b,
+                                           const int it_begin, const int it_end, const bool first_chunk,
+                                           const bool last_chunk) {
+  using G = Fast2Geom<NX, NY, R>;
+  constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, LH = G::LH;
+  real* exch = reinterpret_cast<real*>(smem);
+  real* errp = exch + G::EXCH;   // [2][2][16]: reference norm / unweighted norm partials
+  real* sact = errp + 64;        // [64]
+  real* red = sact + 64;         // [32]
+  real* Ul = red + 32;
+  real* Vl = Ul + SZ;
+  real* Tl = Vl + SZ;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool active = lane < LH;
+  const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
+  const int j0 = 2 * la + 1;                 // rows j0 (a = 0) and j0 + 1 (a = 1)
+  const int i0 = w * R + 1;
+  const size_t off = (size_t)b * A.ncell;
+  real* __restrict__ gu = A.u + off;
+  real* __restrict__ gv = A.v + off;
+  real* __restrict__ gp = A.p + off;
+  real* __restrict__ gS = A.S + off;
+  auto ex = [&](int buf, int wave, int side, int a) -> real* {
+    return exch + (((buf * NW + wave) * 2 + side) * 2 + a) * 64;
+  };
+
+  // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
+  for (int c = tid; c < SX * SY; c += NT) {
+    const int jj = c / SX, ii = c - jj * SX;
+    Ul[ii * SY + jj] = gu[c];
+    Vl[ii * SY + jj] = gv[c];
+    Tl[ii * SY + jj] = gS[c];
+  }
+  if (tid < 64) errp[tid] = 0;
+  real p[2][RW];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int k = 0; k < RW; k++) p[a][k] = active ? gp[(j0 + a) * SX + i0 + k] : real(0);
+
+  // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----------
+  real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
+  if (KIND == 0 && !first_chunk) {   // later chunks of a scheduled step reuse the conditioned vector
+    if (tid < A.n_sgts) sact[tid] = A.a_last[(size_t)b * A.n_sgts + tid];
+  } else if (KIND == 0) {
+    const int n = A.n_sgts;
+    const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
+    real mean = 0;
+    for (int k = 0; k < n; k++) mean += src[k];
+    mean /= (real)n;
+    real m = 1;
+    for (int k = 0; k < n; k++) {
+      real t = bcn_abs(src[k] - mean) / A.C;
+      m = t > m ? t : m;
+    }
+    real mine = (tid < n) ? (src[tid] - mean) / m : real(0);
+    __syncthreads();
+    if (tid < n) {
+      sact[tid] = mine;
+      A.a_last[(size_t)b * n + tid] = mine;
+      if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
+    }
+  } else {
+    const int act = (A.iactions && first_chunk) ? A.iactions[b] : A.ia_last[b];
+    __syncthreads();
+    if (tid == 0 && first_chunk) A.ia_last[b] = act;
+    if (act == 0) { u_b = A.u_max; u_t = -A.u_max; }
+    if (act == 1) { u_b = -A.u_max; u_t = A.u_max; }
+    if (act == 2) { v_r = A.u_max; v_l = -A.u_max; }
+    if (act == 3) { v_r = -A.u_max; v_l = A.u_max; }
+  }
+  __syncthreads();
+
+  const real dt = A.dt, rdx = A.rdx, rdy = A.rdy, rdx2 = A.rdx2, rdy2 = A.rdy2;
+  const real cx = A.cx, cy = A.cy;
+  // lanes past the top row pair keep phi = 0: zero coefficients and zero rhs
+  const real cxl = active ? cx : real(0), cyl = active ? cy : real(0);
+  // y-ghost coefficients of the centre value: bottom row (lane 0, a = 0) always Neumann; top row
+  // (last active lane, a = 1) Neumann for rayleigh, Dirichlet 0 for mixing
+  const real cB0 = (lane == 0) ? cy : real(0);
+  const real cB1 = (lane == LH - 1 && KIND == 0) ? cy : real(0);
+  // error weights of this lane's two rows (ghosts copy their interior neighbour)
+  const real wl0 = active ? real(1) + (lane == 0 ? 1 : 0) : real(0);
+  const real wl1 = active ? real(1) + ((lane == LH - 1 && KIND == 0) ? 1 : 0) : real(0);
+  const real fW = (active && w == 0) ? real(1) : real(0);
+  const real fE = (active && w == NW - 1) ? real(1) : real(0);
+  // weights of the strip's first / last column (the ghost column next to a wall column counts too)
+  const real cW0 = wl0 * (1 + fW), cW1 = wl1 * (1 + fW), cE0 = wl0 * (1 + fE), cE1 = wl1 * (1 + fE);
+  const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
+
+  int status = 0;
+  int xb = 0;
+#ifdef BCN_STAMP
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tl = __builtin_amdgcn_s_memtime();
+#define BCN_PH(x) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); seg[x] += t__ - tl; tl = t__; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BCN_PH(x)
+#endif
+  if (!first_chunk) status = A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
+  const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
+  unsigned long long cyc_j = 0;
+  for (int it = it_begin; it < it_end && status == 0; it++) {
+    // ---- boundary conditions on the LDS fields (rayleigh.py:180-202 / mixing.py:153-171) ------
+    for (int jj = 1 + tid; jj <= NY; jj += NT) {
+      Ul[1 * SY + jj] = 0;
+      Ul[(NX + 1) * SY + jj] = 0;
+      if (jj >= 2) {
+        Vl[0 * SY + jj] = 2 * v_l - Vl[1 * SY + jj];
+        Vl[(NX + 1) * SY + jj] = 2 * v_r - Vl[NX * SY + jj];
+      }
+      Tl[0 * SY + jj] = Tl[1 * SY + jj];
+      Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
+    }
+    for (int ii = 1 + tid; ii <= NX + 1; ii += NT) {
+      const bool wall = (ii == 1) || (ii == NX + 1);
+      const real utop = wall ? real(0) : Ul[ii * SY + NY];
+      const real ubot = wall ? real(0) : Ul[ii * SY + 1];
+      Ul[ii * SY + NY + 1] = 2 * u_t - utop;
+      Ul[ii * SY + 0] = 2 * u_b - ubot;
+      if (ii <= NX) {
+        Vl[ii * SY + NY + 1] = 0;
+        Vl[ii * SY + 1] = 0;
+        if (KIND == 0) {
+          Tl[ii * SY + NY + 1] = 2 * A.Tc - Tl[ii * SY + NY];
+          const int k = (ii - 1) / A.nx_sgts;
+          if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
+        } else {
+          Tl[ii * SY + NY + 1] = Tl[ii * SY + NY];
+          Tl[ii * SY + 0] = Tl[ii * SY + 1];
+        }
+      }
+    }
+    ex(xb, w, 1, 0)[lane] = p[0][RW - 1];
+    ex(xb, w, 1, 1)[lane] = p[1][RW - 1];
+    __syncthreads();
+    BCN_PH(0)
+
+    // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* (registers, then LDS) ---
+    real us[2][RW], vs[2][RW];
+    {
+      const real pWh0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0);
+      const real pWh1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
+      xb ^= 1;
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        __builtin_amdgcn_sched_barrier(0);   // finish one row before loading the next: register pressure
+        const int j = j0 + a;
+        real ur[RW + 2], uS[RW + 1], uN[RW], vr[RW + 2], vN[RW + 1], vS[RW];
+#pragma unroll
+        for (int k = 0; k < RW + 2; k++) { ur[k] = Ul[(i0 - 1 + k) * SY + j]; vr[k] = Vl[(i0 - 1 + k) * SY + j]; }
+#pragma unroll
+        for (int k = 0; k < RW + 1; k++) { uS[k] = Ul[(i0 + k) * SY + j - 1]; vN[k] = Vl[(i0 - 1 + k) * SY + j + 1]; }
+#pragma unroll
+        for (int k = 0; k < RW; k++) { uN[k] = Ul[(i0 + k) * SY + j + 1]; vS[k] = Vl[(i0 + k) * SY + j - 1]; }
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+          const int i = i0 + k;
+          const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
+          const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
+          const real pc = p[a][k];
+          const real pW = (k > 0) ? p[a][k > 0 ? k - 1 : 0] : (a == 0 ? pWh0 : pWh1);
+          // south neighbour of the lower row lives in the lane below (its upper row)
+          const real pS = (a == 0) ? from_below(p[1][k], p[1][k]) : p[0][k];
+          {
+            real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+            real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
+            real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
+            real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
+            real pres = (pc - pW) * rdx;
+            us[a][k] = (i >= 2) ? uc + dt * (diff - conv - pres) : real(0);
+          }
+          {
+            real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+            real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
+            real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
+            real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
+            real pres = (pc - pS) * rdy;
+            const real buoy = (KIND == 0) ? Tl[i * SY + j] : real(0);
+            vs[a][k] = (j >= 2) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // every read of the old u, v is done: u*, v* take their place
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+          Ul[(i0 + k) * SY + j0 + a] = us[a][k];
+          Vl[(i0 + k) * SY + j0 + a] = vs[a][k];
+        }
+    }
+    __syncthreads();
+
+    // ---- Poisson rhs from u*, v* in LDS (u*[1,.] = u*[nx+1,.] = v*[.,1] = v*[.,ny+1] = 0 are the
+    //      wall values the BC pass left there) ------------------------------------------------
+    real nb[2][RW];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const int j = j0 + a;
+#pragma unroll
+      for (int k = 0; k < RW; k++) {
+        const int c = (i0 + k) * SY + j;
+        const real div = (Ul[c + SY] - Ul[c]) * rdx + (Vl[c + 1] - Vl[c]) * rdy;
+        nb[a][k] = active ? -A.cb * div : real(0);
+      }
+    }
+
+    BCN_PH(1)
+    const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
+    // ---- Jacobi sweeps: one barrier per sweep, phi ping-pong in registers ---------------------
+    // The residual is evaluated only on the sweeps that can pass the test (A.conv_plan, see ns2d_fast.hip); a sweep
+    // that evaluates it does so behind its own barrier, with the arithmetic the fused form had.
+    real phA[2][RW], phB[2][RW];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int k = 0; k < RW; k++) phA[a][k] = 0;
+    real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
+    real hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
+    int itp = 0;
+    bool finalB = false;
+    int k_prev = -1;
+    float l2u_prev = 0, l2w_prev = 0;
+    int skip_left = 0;
+    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+    constexpr int JMAX = 256;
+    // lower row (a = 0): south = lane below's upper row (DPP), north = own upper row;
+    // upper row (a = 1): south = own lower row, north = lane above's lower row (DPP)
+#define BCN_CELL(DST, SRC, K, EV, WV)                                                                \
+    {                                                                                                \
+      const real c0 = SRC[0][K], c1 = SRC[1][K];                                                     \
+      real sn0, sn1;   /* south + north of the lower / upper row */                                  \
+      add_pair_neighbours(c0, c1, sn0, sn1);                                                         \
+      if (EQ) {                                                                                      \
+        DST[0][K] = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + nb[0][K]);                           \
+        DST[1][K] = cxl * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                           \
+      } else {                                                                                       \
+        DST[0][K] = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + nb[0][K]));                     \
+        DST[1][K] = cxl * (EV##1 + WV##1) + (cyl * sn1 + (cB1 * c1 + nb[1][K]));                     \
+      }                                                                                              \
+    }
+#define BCN_CELLS(SRC, DST)                                                                          \
+      _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
+        const real e0 = SRC[0][k + 1], e1 = SRC[1][k + 1], w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];  \
+        BCN_CELL(DST, SRC, k, e, w)                                                                  \
+      }                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);   /* halo-dependent part stays behind the interior cells */ \
+      hW0 = (w > 0) ? hW0r : SRC[0][0];                                                              \
+      hW1 = (w > 0) ? hW1r : SRC[1][0];                                                              \
+      hE0 = (w < NW - 1) ? hE0r : SRC[0][RW - 1];                                                     \
+      hE1 = (w < NW - 1) ? hE1r : SRC[1][RW - 1];                                                     \
+      {                                                                                              \
+        const real e0 = SRC[0][1], e1 = SRC[1][1], w0 = hW0, w1 = hW1;                               \
+        BCN_CELL(DST, SRC, 0, e, w)                                                                  \
+      }                                                                                              \
+      {                                                                                              \
+        const real e0 = hE0, e1 = hE1, w0 = SRC[0][RW - 2], w1 = SRC[1][RW - 2];                       \
+        BCN_CELL(DST, SRC, RW - 1, e, w)                                                              \
+      }                                                                                              \
+      ex(xb, w, 0, 0)[lane] = DST[0][0];                                                             \
+      ex(xb, w, 0, 1)[lane] = DST[1][0];                                                             \
+      ex(xb, w, 1, 0)[lane] = DST[0][RW - 1];                                                         \
+      ex(xb, w, 1, 1)[lane] = DST[1][RW - 1];
+#define BCN_HALO_READS                                                                               \
+      hW0r = ex(xb, wm, 1, 0)[lane];                                                                 \
+      hW1r = ex(xb, wm, 1, 1)[lane];                                                                 \
+      hE0r = ex(xb, wp, 0, 0)[lane];                                                                 \
+      hE1r = ex(xb, wp, 0, 1)[lane];                                                                 \
+      xb ^= 1;
+#define BCN_FAST(SRC, DST) { BCN_CELLS(SRC, DST) __syncthreads(); itp++; BCN_HALO_READS }
+#define BCN_CHECK(SRC, DST, DST_IS_B)                                                                \
+    {                                                                                                \
+      BCN_CELLS(SRC, DST)                                                                            \
+      real acc0 = 0, acc1 = 0;                                                                       \
+      _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
+        const real d0 = DST[0][k] - SRC[0][k], d1 = DST[1][k] - SRC[1][k];                           \
+        acc0 += d0 * d0; acc1 += d1 * d1;                                                            \
+      }                                                                                              \
+      const real pI = wl0 * acc0 + wl1 * acc1;                                                       \
+      real dW0 = DST[0][0] - SRC[0][0], dW1 = DST[1][0] - SRC[1][0];                                 \
+      real dE0 = DST[0][RW - 1] - SRC[0][RW - 1], dE1 = DST[1][RW - 1] - SRC[1][RW - 1];                 \
+      dW0 *= dW0; dW1 *= dW1; dE0 *= dE0; dE1 *= dE1;                                                \
+      const real part = pI + (cW0 * dW0 + cW1 * dW1) + (cE0 * dE0 + cE1 * dE1);                      \
+      const real tot63 = wave_sum_lane63<real>(part);                                                \
+      if (lane == 63) errp[xb * 32 + w] = tot63;                                                     \
+      if (A.conv_plan == 1) {   /* unweighted interior norm (lanes past the top row pair hold zeros) */ \
+        const real totu63 = wave_sum_lane63<real>((acc0 + acc1) + (dW0 + dW1) + (dE0 + dE1));        \
+        if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                             \
+      }                                                                                              \
+      __syncthreads();                                                                               \
+      itp++;                                                                                         \
+      const real eW = errp[xb * 32 + (lane & 15)];                                                   \
+      const real eU = (A.conv_plan == 1) ? errp[xb * 32 + 16 + (lane & 15)] : real(0);               \
+      BCN_HALO_READS                                                                                 \
+      const real err = read_lane(row16_sum<real>(eW), 15);                                           \
+      if (!(err > A.tol)) {                                                                          \
+        if (skip_left > 0) status |= BCN_ST_PLAN;                                                    \
+        finalB = DST_IS_B; break;                                                                    \
+      }                                                                                              \
+      if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; }                       \
+      n = 0;                                                                                         \
+      if (skip_left > 0) {                                                                           \
+        skip_left--;                                                                                 \
+      } else if (A.conv_plan > 0) {                                                                  \
+        const float l2w = __log2f((float)err);                                                       \
+        float l2u = 0;                                                                               \
+        if (A.conv_plan == 1) l2u = __log2f((float)read_lane(row16_sum<real>(eU), 15));              \
+        int j = 0;                                                                                   \
+        if (k_prev >= 0) {                                                                           \
+          const float rg = 1.f / (float)(itp - 1 - k_prev);                                          \
+          if (A.conv_plan == 1) {                                                                    \
+            const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;                       \
+            if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX;   \
+          } else {                                                                                   \
+            const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;                       \
+            int jw = 0;                                                                              \
+            if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX;  \
+            j = jw - 1 - (jw >> 4);                                                                  \
+            j = j > 0 ? j : 0;                                                                       \
+          }                                                                                          \
+        }                                                                                            \
+        j = __builtin_amdgcn_readfirstlane(j);                                                       \
+        l2u_prev = l2u; l2w_prev = l2w; k_prev = itp - 1;                                            \
+        if (A.verify_conv) skip_left = j; else n = j;                                                \
+      }                                                                                              \
+    }
+    for (;;) {
+      int n;
+      BCN_CHECK(phA, phB, true)
+      if (n == 0) {
+        BCN_CHECK(phB, phA, false)
+        n &= ~1;
+      } else {
+        BCN_FAST(phB, phA)
+        n = (n - 1) & ~1;
+      }
+      if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
+      for (; n > 0; n -= 2) {
+        BCN_FAST(phA, phB)
+        BCN_FAST(phB, phA)
+      }
+    }
+#undef BCN_CHECK
+#undef BCN_FAST
+#undef BCN_HALO_READS
+#undef BCN_CELLS
+#undef BCN_CELL
+    if (finalB) {
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < RW; k++) phA[a][k] = phB[a][k];
+    }
+    hW0 = hW0r; hW1 = hW1r;   // west halo of the final phi (unused by wave 0)
+    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
+
+    cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
+    BCN_PH(2)
+    // ---- p += phi, corrector: u = u* - dt dphi/dx, v = v* - dt dphi/dy (in place in LDS) -------
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const int j = j0 + a;
+#pragma unroll
+      for (int k = 0; k < RW; k++) {
+        const int i = i0 + k;
+        const real ph = phA[a][k];
+        const real pw = (k > 0) ? phA[a][k > 0 ? k - 1 : 0] : (a == 0 ? hW0 : hW1);
+        const real ps = (a == 0) ? from_below(phA[1][k], phA[1][k]) : phA[0][k];
+        p[a][k] += ph;
+        if (active) {
+          const int c = i * SY + j;
+          if (i >= 2) Ul[c] = Ul[c] - dt * (ph - pw) * rdx;
+          if (j >= 2) Vl[c] = Vl[c] - dt * (ph - ps) * rdy;
+        }
+      }
+    }
+    __syncthreads();
+
+    BCN_PH(3)
+    // ---- transport: explicit part of every cell, then the ordered part by one wave ------------
+    {
+      real Ac[2][RW];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+          const int c = (i0 + k) * SY + j0 + a;
+          const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
+          const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
+          const real expl = A.ksc * ((TE - 2 * T0) * rdx2 + (TN - 2 * T0) * rdy2) -
+                            (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
+                            (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
+          Ac[a][k] = T0 + dt * expl;
+        }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int k = 0; k < RW; k++) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
+      }
+    }
+    __syncthreads();
+    BCN_PH(4)
+    if (w == 0)
+      transport_chain2<real, NX, NY>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+                                     dt * A.ksc * rdy2, real(0.5) * dt * rdy);
+    __syncthreads();
+    BCN_PH(5)
+  }
+
+  // ---- store: LDS [i][j] -> HBM [j][i]; p and its ghosts -------------------------------------
+  for (int c = tid; c < SX * SY; c += NT) {
+    const int jj = c / SX, ii = c - jj * SX;
+    gu[c] = Ul[ii * SY + jj];
+    gv[c] = Vl[ii * SY + jj];
+    gS[c] = Tl[ii * SY + jj];
+  }
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int k = 0; k < RW; k++) {
+        const int i = i0 + k, j = j0 + a, c = j * SX + i;
+        const real dp = p[a][k] - gp[c];
+        if (i == 1) gp[c - 1] += dp;
+        if (i == NX) gp[c + 1] += dp;
+        if (j == 1) gp[c - SX] += dp;
+        if (j == NY && KIND == 0) gp[c + SX] += dp;
+        gp[c] = p[a][k];
+      }
+  }
+  __syncthreads();
+  if (last_chunk) {
+    ns2d_finish<real, NT>(A, b, gu, gv, gS, status, red);
+  } else if (tid == 0) {
+    A.status[b] = status;
+  }
+  if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
+    A.cyc[2 * (size_t)b] += cyc_j;
+    A.cyc[2 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
+  }
+#ifdef BCN_STAMP   // diagnostic build only: cycles per timestep of each phase over the first obs entries
+  __syncthreads();
+  if (tid == 0 && A.obs_out)
+    for (int q = 0; q < 6; q++) A.obs_out[(size_t)b * A.n_obs + q] = (real)seg[q] / (real)(it_end - it_begin);
+#endif
+}
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__device__ __forceinline__ void fast2_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
+                                           const bool first_chunk, const bool last_chunk, char* smem) {
+  using G = Fast2Geom<NX, NY, R>;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (G::RL != R && w == G::NW - 1)
+    fast2_body<real, NX, NY, R, G::RL, KIND, EQ>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
+  else
+    fast2_body<real, NX, NY, R, R, KIND, EQ>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
+}
+
+// plain launch: one workgroup per replica, the whole action step
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
+  fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, 0, A.ndt_act, true, true, smem);
+}
+
+// ticketed chunk scheduler (ns2d_sched.h): persistent workgroups draw (chunk, replica) units
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+__global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch,
+                                                                          int nchunk) {
+  using G = Fast2Geom<NX, NY, R>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // two words at the end of the `red` scratch row (block_sum uses red[0..NW), the transport sink red[16..17])
+  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) + G::EXCH + 128 + 24);
+  ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
+    fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
+  });
+}
+
+template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  using G = Fast2Geom<NX, NY, R>;
+  const size_t lds = G::lds_elems() * sizeof(real);
+  NS2DArgs<real> c = a;
+  if (!c.sweeps) c.sweeps = c.sweeps_int;
+  if (const char* e = getenv("BCN_VERIFY_CONV")) c.verify_conv = atoi(e);
+  const SchedParams sp = ns2d_sched_params(a);
+  const int q = sp.q_set ? sp.q : 20;   // 100x100: 20 timesteps per chunk measured best (37.7 vs 38.2 ms at 10)
+  if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * q && a.sched_ctl) {
+    auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ>;
+    static unsigned long long set2 = 0;
+    if (ns2d_first_on_device(set2)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nchunk = a.ndt_act / q;
+    c.sched_q = q;
+    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
+    hipLaunchKernelGGL(ks, dim3(sp.grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
+    BCN_HIP(hipGetLastError());
+    if (a.launched) *a.launched = "ns2d_fast2_sched";
+    return BCN_OK;
+  }
+  if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
+  auto k = ns2d_fast2_step<real, NX, NY, R, KIND, EQ>;
+  static unsigned long long set = 0;
+  if (ns2d_first_on_device(set)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  BCN_HIP(hipGetLastError());
+  if (a.launched) *a.launched = "ns2d_fast2_step";
+  return BCN_OK;
+}
+
+template <typename real, int NX, int NY, int R, int KIND>
+int launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  // dx == dy (every reference configuration): one multiply per cell instead of two
+  if (a.cx == a.cy) return launch_fast2_eq<real, NX, NY, R, KIND, true>(a, batch, s);
+  return launch_fast2_eq<real, NX, NY, R, KIND, false>(a, batch, s);
+}
+
+}  // namespace

@@ -1,0 +1,145 @@
+"""Register-resident kernels for grids that are not built into libbeacon_hip.so.
+
+The reference takes any domain size (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: nx = 100 L, ny = 100 H);
+the register-resident kernels are templates over the grid (csrc/ns2d_fast_impl.h: one row per lane, ny <= 64;
+csrc/ns2d_fast2_impl.h: two rows per lane, 64 < ny <= 128, ny even).  libbeacon_hip.so carries the metric grid and the
+reference's defaults; for any other grid `plugin_for()` compiles csrc/jit/ns2d_jit.hip for that ONE grid with hipcc
+(about 30 s, once: the shared object is cached in beacon_amd/_jit/, keyed by a hash of its sources and flags, and
+travels with the tree like the library itself) and hands its launcher to the library through bcn_set_fast_plugin.
+No hipcc, BEACON_JIT=0 or a grid the mapping cannot hold (ny > 128, odd ny > 64, LDS) -> None: the env keeps the
+generic kernel (still on the GPU; only slower)."""
+import ctypes as C
+import fcntl
+import hashlib
+import os
+import subprocess
+
+from . import build as _build
+
+JIT_DIR = os.path.join(_build.PKG, "_jit")
+JIT_SRC = os.path.join(_build.CSRC, "jit", "ns2d_jit.hip")
+LDS_BYTES = 160 * 1024
+_LOADED = {}
+
+
+def _up16(x):
+    return (x + 15) // 16 * 16
+
+
+def _lds_rows1(nx, ny, nw, esz, gf):
+    sy, sz = ny + 2, (nx + 2) * (ny + 2) + 16
+    misc = 2 * nw * 2 * 64 + 160 + 16
+    front = _up16(max(misc, 63 * sy + 1))
+    back = (ny + 4 + 1) * sy
+    if gf == 1:
+        return _up16(misc) * esz
+    if gf == 2:
+        return (_up16(misc) + 2 * sz) * esz
+    return (front + 3 * sz + back) * esz
+
+
+def choose(nx, ny, f64, kind):
+    """Mapping of an nx x ny grid onto one workgroup: dict(rows, R, gf) or None.  Waves: 8 (two per SIMD, 256 VGPRs
+    each) where the strips fit the register file, else 12 or 16; the last wave may take fewer columns (>= 3)."""
+    esz = 8 if f64 else 4
+    if nx < 6 or ny < 4:
+        return None
+    if ny <= 64:
+        for nw, rmax in ((8, 16 if f64 else 26), (12, 18), (16, 12), (10, 20), (6, 26), (5, 26), (4, 26), (3, 26), (2, 26)):
+            if f64 and nw > 8:
+                continue
+            r = -(-nx // nw)
+            rl = nx - (nw - 1) * r
+            if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
+                continue
+            for gf in ((0,) if not f64 else (2, 1)):
+                if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
+                    return {"rows": 1, "R": r, "gf": gf, "nw": nw}
+        return None
+    if ny <= 128 and ny % 2 == 0 and not f64:
+        for nw, rmax in ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26)):
+            r = -(-nx // nw)
+            rl = nx - (nw - 1) * r
+            if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
+                continue
+            if (2 * nw * 4 * 64 + 160 + 3 * (nx + 2) * (ny + 2)) * esz <= LDS_BYTES:
+                return {"rows": 2, "R": r, "gf": 0, "nw": nw}
+    return None
+
+
+def _signature(defs):
+    h = hashlib.sha256()
+    h.update(repr((_build.ARCH, _build.FLAGS, _build.FILE_FLAGS.get("ns2d_fast.hip"), sorted(defs.items()))).encode())
+    for f in sorted([JIT_SRC] + [os.path.join(_build.CSRC, n) for n in os.listdir(_build.CSRC) if n.endswith(".h")] +
+                    [os.path.join(_build.INC, n) for n in os.listdir(_build.INC) if n.endswith(".h")]):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def build_plugin(nx, ny, f64, kind, verbose=False):
+    """Path of the shared object for this grid (compiling it if needed), or None."""
+    m = choose(nx, ny, f64, kind)
+    if m is None or os.environ.get("BEACON_JIT", "1") == "0":
+        return None
+    defs = {"BCN_JIT_ROWS": m["rows"], "BCN_JIT_REAL": "double" if f64 else "float", "BCN_JIT_NX": nx, "BCN_JIT_NY": ny,
+            "BCN_JIT_R": m["R"], "BCN_JIT_KIND": kind, "BCN_JIT_GF": m["gf"]}
+    name = "ns2d_%dx%d_%s_k%d_r%d_%s.so" % (nx, ny, "f64" if f64 else "f32", kind, m["R"], _signature(defs))
+    path = os.path.join(JIT_DIR, name)
+    if os.path.exists(path):
+        return path
+    cc = _build.hipcc()
+    if cc is None or os.environ.get("BEACON_NO_BUILD") == "1":
+        return None
+    os.makedirs(JIT_DIR, exist_ok=True)
+    with open(os.path.join(JIT_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)              # N ranks of one node asking for the same grid
+        try:
+            if os.path.exists(path):
+                return path
+            tmp = "%s.tmp%d" % (path, os.getpid())
+            cmd = ([cc] + _build.FLAGS + _build.FILE_FLAGS.get("ns2d_fast.hip", []) +
+                   ["-D%s=%s" % kv for kv in sorted(defs.items())] + ["-I", _build.INC, "-shared", JIT_SRC, "-o", tmp])
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(tmp, path)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return path
+
+
+class Plugin(object):
+    def __init__(self, path):
+        self.path = path
+        self.lib = C.CDLL(path)                       # bcn_set_error resolves against libbeacon_hip.so (RTLD_GLOBAL)
+        self.lib.bcn_jit_scratch_elems.restype = C.c_size_t
+        self.lib.bcn_jit_lds_bytes.restype = C.c_size_t
+        self.fn = C.cast(self.lib.bcn_jit_launch, C.c_void_p)
+        self.scratch = int(self.lib.bcn_jit_scratch_elems())
+        self.lds = int(self.lib.bcn_jit_lds_bytes())
+
+
+def plugin_for(nx, ny, f64, kind):
+    """Loaded plugin (kept alive for the life of the process) for this grid, or None."""
+    key = (nx, ny, bool(f64), kind)
+    if key not in _LOADED:
+        path = build_plugin(nx, ny, f64, kind)
+        p = Plugin(path) if path else None
+        if p is not None and p.lds > LDS_BYTES:
+            p = None
+        _LOADED[key] = p
+    return _LOADED[key]
+
+
+# grids of the -m gpu tests (tests/test_gpu_parity.py::test_jit_grids_*): built by __graft_entry__.build() so that
+# they ship with the tree; any other grid compiles at its first use
+TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 64, False, 0), (110, 64, True, 0),
+              (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0)]
+
+
+def prebuild(grids=None, verbose=False):
+    """Compile the plugins of a list of (nx, ny, f64, kind) grids (used by __graft_entry__.build() for the grids the
+    tests touch, so that they ship with the tree)."""
+    return [build_plugin(nx, ny, f64, kind, verbose) for nx, ny, f64, kind in (grids or TEST_GRIDS)]

@@ -158,6 +158,17 @@ class VecEnv(object):
         results do not depend on it."""
         _lib.check(self.lib.bcn_set_sched(self.h, int(mode), int(grid), int(q), int(lpt_min_batch)))
 
+    def _attach_plugin(self, kind):
+        """2D envs: a grid without a built-in register-resident kernel gets one compiled for it (beacon_amd/jit.py);
+        when that is not possible the generic kernel stays selected."""
+        if self.lib.bcn_set_variant(self.h, 1) == 1:
+            return
+        from . import jit
+        p = jit.plugin_for(self.nx, self.ny, self.tdtype == torch.float64, kind)
+        if p is not None:
+            _lib.check(self.lib.bcn_set_fast_plugin(self.h, p.fn, p.scratch))
+            self._plugin = p
+
     def set_option(self, name, value):
         """Solver options by name (include/beacon_hip.h: bcn_set_option), e.g. ("conv_plan", 0)."""
         _lib.check(self.lib.bcn_set_option(self.h, name.encode(), int(value)))
@@ -283,6 +294,7 @@ class VecRayleigh(VecEnv):
         self.cfg = c
         _lib.check(self.lib.bcn_rayleigh_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
                                                 C.byref(self.h)))
+        self._attach_plugin(0)
 
     def set_ndt_act(self, n):
         """Test hook: shorten the action step (the goldens for big grids use ndt_act=5)."""
@@ -349,6 +361,7 @@ class VecMixing(VecEnv):
         self.cfg = c
         _lib.check(self.lib.bcn_mixing_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
                                               C.byref(self.h)))
+        self._attach_plugin(1)
 
     def set_ndt_act(self, n):
         self.close()

@@ -176,6 +176,13 @@ BCN_API int bcn_set_variant(bcn_env_t h, int variant);
  * inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463) and in the whole replica (all chunks),
  * uint64[B][2] on the host; zeros for kernels that do not count (generic 2D kernel, 1D envs). */
 BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
+/* Register-resident kernel for a grid that is not built into the library.  The reference takes any L, H
+ * (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: 100 L, 100 H); csrc/jit/ns2d_jit.hip is compiled for ONE
+ * grid into its own shared object (beacon_amd/jit.py does so on demand and caches it) whose
+ *   int bcn_jit_launch(const void* step_args, int batch, void* stream)
+ * is passed here together with bcn_jit_scratch_elems().  Selects variant 1; launch_fn = NULL restores the built-in
+ * choice.  The plugin must outlive the handle. */
+BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_elems);
 /* Solver options of the 2D envs (no reference counterpart), by name:
  *   "conv_plan"   which Jacobi sweeps evaluate the residual sum((phi - phin)^2) of rayleigh.py:448-449 / mixing.py:457-458
  *                 in the register-resident kernels: 0 = every sweep, as the reference does; 1 = every sweep that can pass

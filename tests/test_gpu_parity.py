@@ -268,6 +268,7 @@ def test_ns2d_generic_other_grids_vs_oracle_f64():
     acts = rng.uniform(-1, 1, (2, B, 5))
     env = V.VecRayleigh(B, DEV, "f64", init, L=3.0, H=1.0, n_sgts=5, ra=5.0e3)
     env.set_ndt_act(NDT)
+    env.set_variant(0)          # this test is about the generic kernel (the grid would get a kernel plugin)
     env.reset()
     oracles = [O.rayleigh(init_fields=init, L=3.0, H=1.0, n_sgts=5, ra=5.0e3) for _ in range(B)]
     for o in oracles:
@@ -550,6 +551,72 @@ def test_convergence_plan_never_skips_a_passing_sweep():
         assert torch.equal(planned[i][1], literal[j][1]) and torch.equal(planned[i][2], literal[j][2])
 
 
+@pytest.mark.parametrize("L,H,dtype,tol", [(1.5, 1.0, "f32", 5e-5), (1.5, 1.0, "f64", F64_TOL), (1.06, 1.0, "f32", 5e-5),
+                                            (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
+                                            (1.2, 2.4, "f32", 5e-5)])
+def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
+    """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
+    instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
+    60x120 (two rows per lane) -- 30 timesteps with distinct actions against the float64 oracle, and against the generic
+    kernel on the same inputs."""
+    B = 6
+    env = V.VecRayleigh(B, DEV, dtype, None, L=L, H=H)
+    env.set_ndt_act(30)
+    assert env.set_variant(1) == 1 and getattr(env, "_plugin", None) is not None, "no kernel plugin for %dx%d" % (env.nx, env.ny)
+    rng = np.random.default_rng(3)
+    x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+    st0 = np.zeros((4, env.nx + 2, env.ny + 2))      # conduction profile + a smooth perturbation (robust sweep counts)
+    st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x * L)[:, None] * np.sin(np.pi * y)[None, :]
+    acts = rng.uniform(-1, 1, (B, 10))
+    out = {}
+    for variant in (1, 0):
+        env.set_variant(variant)
+        env.reset()
+        env.set_state(np.tile(ref_to_dev(st0)[None], (B, 1, 1, 1)))
+        obs, rwd, _, _, _ = env.step(acts)
+        env.check_status()
+        out[variant] = (obs.double().cpu().numpy(), rwd.double().cpu().numpy(), dev2ref(env.get_state()), env.sweeps.cpu().numpy())
+        if variant == 1:
+            assert env.kernel_name in ("ns2d_fast_step", "ns2d_fast2_step")
+    for b in range(B):
+        o = O.rayleigh(init=False, L=L, H=H)
+        o.cfg.ndt_act = 30
+        o.reset_fields()
+        o.st[:4] = st0
+        ob, rw, _, _, _ = o.step(acts[b].tolist())
+        for i, F in enumerate("uvpT"):
+            assert maxdiff(out[1][2][b][i], o.st[i]) <= tol * (50 if F == "p" else 1), (b, F)
+        n = 3 * env.nx_obs_pts * env.ny_obs_pts
+        assert maxdiff(out[1][0][b][-n:], ob[-n:]) <= tol and abs(out[1][1][b] - rw) <= max(1e-8, 4 * tol)
+        assert np.all(np.abs(out[1][3][b] - o.itp) <= (1 if dtype == "f64" else np.maximum(3, 0.02 * o.itp)))
+    assert maxdiff(out[1][2], out[0][2]) <= 50 * tol
+    env.close()
+
+
+def test_jit_grid_mixing_vs_oracle():
+    """mixing(L=1.0, H=1.1): 100x110, two rows per lane, strips of 13 columns (the last wave 9); 40 timesteps from rest."""
+    env = V.VecMixing(4, DEV, "f32", L=1.0, H=1.1)
+    env.set_ndt_act(40)
+    assert env.set_variant(1) == 1 and getattr(env, "_plugin", None) is not None
+    env.reset()
+    a = np.arange(4)
+    obs, rwd, _, _, _ = env.step(a)
+    env.check_status()
+    assert env.kernel_name == "ns2d_fast2_step"
+    st = dev2ref(env.get_state())
+    sw = env.sweeps.cpu().numpy()
+    for b in range(4):
+        o = O.mixing(L=1.0, H=1.1)
+        o.cfg.ndt_act = 40
+        o.reset()
+        ob, rw, _, _, _ = o.step(int(a[b]))
+        for i, F in enumerate("uvpC"):
+            assert maxdiff(st[b][i], o.st[i]) <= 2e-4 * (50 if F == "p" else 1), (b, F)
+        assert abs(float(rwd[b]) - rw) <= 1e-5
+        assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(3, 0.02 * o.itp)), b
+    env.close()
+
+
 @pytest.mark.parametrize("L,nx", [(2.0, 100), (3.0, 150), (4.0, 200)])
 def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
     """Register-resident instantiations for the reference's other natural aspect ratios (nx = 50 L, ny = 50):
@@ -602,6 +669,7 @@ def test_rayleigh_odd_configs_generic_vs_oracle_f64(L, H, n_sgts, ra):
     acts = rng.uniform(-1, 1, (2, B, n_sgts))
     env = V.VecRayleigh(B, DEV, "f64", init, L=L, H=H, n_sgts=n_sgts, ra=ra)
     env.set_ndt_act(NDT)
+    env.set_variant(0)          # this test is about the generic kernel (some of these grids would get a kernel plugin)
     env.reset()
     oracles = [O.rayleigh(init_fields=init, L=L, H=H, n_sgts=n_sgts, ra=ra) for _ in range(B)]
     for o in oracles:
