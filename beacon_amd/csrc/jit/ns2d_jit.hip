@@ -2,7 +2,7 @@
 // libbeacon_hip.so, compiled on demand by beacon_amd/jit.py into its own small shared object:
 //   hipcc ... -DBCN_JIT_ROWS=1|2 -DBCN_JIT_REAL=float|double -DBCN_JIT_NX=.. -DBCN_JIT_NY=.. -DBCN_JIT_R=.. -DBCN_JIT_KIND=0|1
 //            [-DBCN_JIT_GF=0|1|2]
-// (ROWS: rows per lane: 1 = ns2d_fast_impl.h, ny <= 64; 2 = ns2d_fast2_impl.h, 64 < ny <= 128, ny even.)
+// (ROWS: rows per lane: 1 = ns2d_fast_impl.h, ny <= 64; 2 = ns2d_fast2_impl.h, 64 < ny <= 128.)
 // The reference takes any L, H (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: 100 L, 100 H); the library
 // hands the argument block of a step to bcn_jit_launch through bcn_set_fast_plugin (include/beacon_hip.h).
 #if BCN_JIT_ROWS == 1

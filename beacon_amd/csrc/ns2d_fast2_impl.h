@@ -34,12 +34,12 @@ using namespace bcn_dpp;
 
 template <int NX, int NY, int R>
 struct Fast2Geom {
-  static_assert(NY % 2 == 0 && NY <= 128, "two rows per lane");
+  static_assert(NY <= 128, "two rows per lane");   // odd ny: the last lane's upper row is the ghost row (inactive)
   static constexpr int NW = (NX + R - 1) / R;
   static constexpr int RL = NX - (NW - 1) * R;   // columns of the last wave
   static_assert(NW <= 16 && RL >= 3 && RL <= R, "at most 16 waves, at least 3 columns each");
   static constexpr int NT = NW * 64;
-  static constexpr int LH = NY / 2;        // active lanes
+  static constexpr int LH = (NY + 1) / 2;  // active lanes
   static constexpr int SY = NY + 2;
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY;
@@ -56,7 +56,8 @@ struct Fast2Geom {
 template <typename real, int NX, int NY>
 __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real* Ul, const real* Vl, real* dummy,
                                                            real c0x, real c1x, real c0y, real c1y) {
-  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = NY / 2, PD = 4;
+  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2, PD = 4;
+  constexpr bool ODD = (NY & 1) != 0;
   constexpr int NSTEP = NX + LH - 1;
   const int lane = threadIdx.x & 63;
   const bool active = lane < LH;
@@ -86,7 +87,8 @@ __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real*
       tp1 = ok ? tn1 : tp1;
       real* dst = ok ? Tl + (cb + t * SY) : dummy;
       dst[0] = tn0;
-      dst[1] = tn1;
+      if (ODD) { real* d1 = (ok && lane < LH - 1) ? dst : dummy; d1[1] = tn1; }   // odd ny: the last lane has no upper row
+      else dst[1] = tn1;
       const int x = at(t + PD);
       a0[q] = Tl[x]; a1[q] = Tl[x + 1]; g[q] = Tl[x - 1];
       u0[q] = Ul[x]; u1[q] = Ul[x + 1];
@@ -111,6 +113,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const bool active = lane < LH;
+  constexpr bool ODD = (NY & 1) != 0;
+  const bool act1 = active && !(ODD && lane == LH - 1);   // the upper row of the pair exists (odd ny: not in the last lane)
   const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
   const int j0 = 2 * la + 1;                 // rows j0 (a = 0) and j0 + 1 (a = 1)
   const int i0 = w * R + 1;
@@ -135,7 +139,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int k = 0; k < RW; k++) p[a][k] = active ? gp[(j0 + a) * SX + i0 + k] : real(0);
+    for (int k = 0; k < RW; k++) p[a][k] = (a == 0 ? active : act1) ? gp[(j0 + a) * SX + i0 + k] : real(0);
 
   // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----------
   real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
@@ -174,13 +178,15 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   const real cx = A.cx, cy = A.cy;
   // lanes past the top row pair keep phi = 0: zero coefficients and zero rhs
   const real cxl = active ? cx : real(0), cyl = active ? cy : real(0);
+  const real cxl1 = act1 ? cx : real(0), cyl1 = act1 ? cy : real(0);   // upper row
   // y-ghost coefficients of the centre value: bottom row (lane 0, a = 0) always Neumann; top row
   // (last active lane, a = 1) Neumann for rayleigh, Dirichlet 0 for mixing
-  const real cB0 = (lane == 0) ? cy : real(0);
-  const real cB1 = (lane == LH - 1 && KIND == 0) ? cy : real(0);
+  const bool top0 = ODD && lane == LH - 1 && KIND == 0, top1 = !ODD && lane == LH - 1 && KIND == 0;   // the top row's Neumann ghost
+  const real cB0 = ((lane == 0) ? cy : real(0)) + (top0 ? cy : real(0));
+  const real cB1 = top1 ? cy : real(0);
   // error weights of this lane's two rows (ghosts copy their interior neighbour)
-  const real wl0 = active ? real(1) + (lane == 0 ? 1 : 0) : real(0);
-  const real wl1 = active ? real(1) + ((lane == LH - 1 && KIND == 0) ? 1 : 0) : real(0);
+  const real wl0 = active ? real(1) + (lane == 0 ? 1 : 0) + (top0 ? 1 : 0) : real(0);
+  const real wl1 = act1 ? real(1) + (top1 ? 1 : 0) : real(0);
   const real fW = (active && w == 0) ? real(1) : real(0);
   const real fE = (active && w == NW - 1) ? real(1) : real(0);
   // weights of the strip's first / last column (the ghost column next to a wall column counts too)
@@ -289,6 +295,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int k = 0; k < RW; k++) {
+          if (a == 1 && !act1) continue;
           Ul[(i0 + k) * SY + j0 + a] = us[a][k];
           Vl[(i0 + k) * SY + j0 + a] = vs[a][k];
         }
@@ -305,7 +312,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       for (int k = 0; k < RW; k++) {
         const int c = (i0 + k) * SY + j;
         const real div = (Ul[c + SY] - Ul[c]) * rdx + (Vl[c + 1] - Vl[c]) * rdy;
-        nb[a][k] = active ? -A.cb * div : real(0);
+        nb[a][k] = (a == 0 ? active : act1) ? -A.cb * div : real(0);
       }
     }
 
@@ -337,10 +344,10 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       add_pair_neighbours(c0, c1, sn0, sn1);                                                         \
       if (EQ) {                                                                                      \
         DST[0][K] = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + nb[0][K]);                           \
-        DST[1][K] = cxl * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                           \
+        DST[1][K] = cxl1 * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                          \
       } else {                                                                                       \
         DST[0][K] = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + nb[0][K]));                     \
-        DST[1][K] = cxl * (EV##1 + WV##1) + (cyl * sn1 + (cB1 * c1 + nb[1][K]));                     \
+        DST[1][K] = cxl1 * (EV##1 + WV##1) + (cyl1 * sn1 + (cB1 * c1 + nb[1][K]));                   \
       }                                                                                              \
     }
 #define BCN_CELLS(SRC, DST)                                                                          \
@@ -471,7 +478,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         const real pw = (k > 0) ? phA[a][k > 0 ? k - 1 : 0] : (a == 0 ? hW0 : hW1);
         const real ps = (a == 0) ? from_below(phA[1][k], phA[1][k]) : phA[0][k];
         p[a][k] += ph;
-        if (active) {
+        if (a == 0 ? active : act1) {
           const int c = i * SY + j;
           if (i >= 2) Ul[c] = Ul[c] - dt * (ph - pw) * rdx;
           if (j >= 2) Vl[c] = Vl[c] - dt * (ph - ps) * rdy;
@@ -501,7 +508,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int k = 0; k < RW; k++) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
+          for (int k = 0; k < RW; k++) if (a == 0 || act1) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
       }
     }
     __syncthreads();
@@ -525,6 +532,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int k = 0; k < RW; k++) {
+        if (a == 1 && !act1) continue;
         const int i = i0 + k, j = j0 + a, c = j * SX + i;
         const real dp = p[a][k] - gp[c];
         if (i == 1) gp[c - 1] += dp;

@@ -2,11 +2,11 @@
 
 The reference takes any domain size (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: nx = 100 L, ny = 100 H);
 the register-resident kernels are templates over the grid (csrc/ns2d_fast_impl.h: one row per lane, ny <= 64;
-csrc/ns2d_fast2_impl.h: two rows per lane, 64 < ny <= 128, ny even).  libbeacon_hip.so carries the metric grid and the
+csrc/ns2d_fast2_impl.h: two rows per lane, 64 < ny <= 128, float32).  libbeacon_hip.so carries the metric grid and the
 reference's defaults; for any other grid `plugin_for()` compiles csrc/jit/ns2d_jit.hip for that ONE grid with hipcc
 (about 30 s, once: the shared object is cached in beacon_amd/_jit/, keyed by a hash of its sources and flags, and
 travels with the tree like the library itself) and hands its launcher to the library through bcn_set_fast_plugin.
-No hipcc, BEACON_JIT=0 or a grid the mapping cannot hold (ny > 128, odd ny > 64, LDS) -> None: the env keeps the
+No hipcc, BEACON_JIT=0 or a grid the mapping cannot hold (ny > 128, float64 above ny = 64, LDS) -> None: the env keeps the
 generic kernel (still on the GPU; only slower)."""
 import ctypes as C
 import fcntl
@@ -56,7 +56,7 @@ def choose(nx, ny, f64, kind):
                 if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
         return None
-    if ny <= 128 and ny % 2 == 0 and not f64:
+    if ny <= 128 and not f64:
         for nw, rmax in ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26)):
             r = -(-nx // nw)
             rl = nx - (nw - 1) * r
@@ -136,10 +136,17 @@ def plugin_for(nx, ny, f64, kind):
 # grids of the -m gpu tests (tests/test_gpu_parity.py::test_jit_grids_*): built by __graft_entry__.build() so that
 # they ship with the tree; any other grid compiles at its first use
 TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 64, False, 0), (110, 64, True, 0),
-              (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0)]
+              (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
+              (100, 105, False, 1)]
 
 
 def prebuild(grids=None, verbose=False):
     """Compile the plugins of a list of (nx, ny, f64, kind) grids (used by __graft_entry__.build() for the grids the
     tests touch, so that they ship with the tree)."""
-    return [build_plugin(nx, ny, f64, kind, verbose) for nx, ny, f64, kind in (grids or TEST_GRIDS)]
+    paths = [build_plugin(nx, ny, f64, kind, verbose) for nx, ny, f64, kind in (grids or TEST_GRIDS)]
+    if grids is None and os.path.isdir(JIT_DIR):      # drop plugins of older source states (their hash no longer matches)
+        keep = {os.path.basename(p) for p in paths if p}
+        for f in os.listdir(JIT_DIR):
+            if f.endswith(".so") and f not in keep:
+                os.remove(os.path.join(JIT_DIR, f))
+    return paths

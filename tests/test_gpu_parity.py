@@ -553,11 +553,11 @@ def test_convergence_plan_never_skips_a_passing_sweep():
 
 @pytest.mark.parametrize("L,H,dtype,tol", [(1.5, 1.0, "f32", 5e-5), (1.5, 1.0, "f64", F64_TOL), (1.06, 1.0, "f32", 5e-5),
                                             (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
-                                            (1.2, 2.4, "f32", 5e-5)])
+                                            (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
-    60x120 (two rows per lane) -- 30 timesteps with distinct actions against the float64 oracle, and against the generic
+    60x120, 110x65 (two rows per lane; odd ny: the last lane holds one row) -- 30 timesteps with distinct actions against the float64 oracle, and against the generic
     kernel on the same inputs."""
     B = 6
     env = V.VecRayleigh(B, DEV, dtype, None, L=L, H=H)
@@ -593,9 +593,11 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     env.close()
 
 
-def test_jit_grid_mixing_vs_oracle():
-    """mixing(L=1.0, H=1.1): 100x110, two rows per lane, strips of 13 columns (the last wave 9); 40 timesteps from rest."""
-    env = V.VecMixing(4, DEV, "f32", L=1.0, H=1.1)
+@pytest.mark.parametrize("H", [1.1, 1.05])
+def test_jit_grid_mixing_vs_oracle(H):
+    """mixing(L=1.0, H=1.1 / 1.05): 100x110 / 100x105 (odd ny), two rows per lane, strips of 13 columns (the last wave 9);
+    40 timesteps from rest."""
+    env = V.VecMixing(4, DEV, "f32", L=1.0, H=H)
     env.set_ndt_act(40)
     assert env.set_variant(1) == 1 and getattr(env, "_plugin", None) is not None
     env.reset()
@@ -606,7 +608,7 @@ def test_jit_grid_mixing_vs_oracle():
     st = dev2ref(env.get_state())
     sw = env.sweeps.cpu().numpy()
     for b in range(4):
-        o = O.mixing(L=1.0, H=1.1)
+        o = O.mixing(L=1.0, H=H)
         o.cfg.ndt_act = 40
         o.reset()
         ob, rw, _, _, _ = o.step(int(a[b]))
