@@ -27,7 +27,7 @@ __attribute__((visibility("default"))) int bcn_jit_launch(const void* args, int 
 #if BCN_JIT_ROWS == 1
   return launch_fast<BCN_JIT_REAL, BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_KIND, BCN_JIT_GF>(a, batch, static_cast<hipStream_t>(stream));
 #else
-  return launch_fast2<BCN_JIT_REAL, BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_KIND>(a, batch, static_cast<hipStream_t>(stream));
+  return launch_fast2<BCN_JIT_REAL, BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_KIND, BCN_JIT_GF>(a, batch, static_cast<hipStream_t>(stream));
 #endif
 }
 
@@ -36,7 +36,7 @@ __attribute__((visibility("default"))) size_t bcn_jit_scratch_elems(void) {
 #if BCN_JIT_ROWS == 1
   return FastGeom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::scratch_elems();
 #else
-  return 0;
+  return Fast2Geom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::scratch_elems();
 #endif
 }
 
@@ -44,7 +44,7 @@ __attribute__((visibility("default"))) size_t bcn_jit_lds_bytes(void) {
 #if BCN_JIT_ROWS == 1
   return FastGeom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::lds_elems() * sizeof(BCN_JIT_REAL);
 #else
-  return Fast2Geom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R>::lds_elems() * sizeof(BCN_JIT_REAL);
+  return Fast2Geom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::lds_elems() * sizeof(BCN_JIT_REAL);
 #endif
 }
 

@@ -72,4 +72,5 @@ template <typename real> int ns2d_launch_fast(const NS2DArgs<real>& a, int batch
 // elements of field scratch one workgroup of the fast path needs for this configuration (0: fields live in LDS)
 template <typename real> size_t ns2d_fast_scratch_elems(const NS2DArgs<real>& a);
 template <typename real> bool ns2d_fast2_supported(const NS2DArgs<real>& a);
+template <typename real> size_t ns2d_fast2_scratch_elems(const NS2DArgs<real>& a);
 template <typename real> int ns2d_launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s);

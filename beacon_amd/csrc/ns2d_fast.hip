@@ -51,6 +51,7 @@ int ns2d_launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
 
 template <typename real>
 size_t ns2d_fast_scratch_elems(const NS2DArgs<real>& a) {
+  if (ns2d_fast2_supported<real>(a)) return ns2d_fast2_scratch_elems<real>(a);
   if (fast_config<real>(a) == 3) return FastGeom<128, 64, BCN_R128D, BCN_GFD>::scratch_elems();
   return 0;
 }

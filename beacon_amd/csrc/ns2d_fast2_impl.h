@@ -32,7 +32,9 @@ namespace {
 
 using namespace bcn_dpp;
 
-template <int NX, int NY, int R>
+// GF = 1 (float64: three float64 fields exceed LDS): u, v, S live in a per-workgroup global scratch (L2-resident), the
+// Poisson rhs in LDS ([cell of the thread][thread]: conflict-free), p and the phi ping-pong in registers.
+template <int NX, int NY, int R, int GF = 0>
 struct Fast2Geom {
   static_assert(NY <= 128, "two rows per lane");   // odd ny: the last lane's upper row is the ghost row (inactive)
   static constexpr int NW = (NX + R - 1) / R;
@@ -45,7 +47,8 @@ struct Fast2Geom {
   static constexpr int SZ = SX * SY;
   // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 64 | sact 64 | red 32 | U V S
   static constexpr int EXCH = 2 * NW * 4 * 64;
-  static constexpr size_t lds_elems() { return (size_t)EXCH + 160 + 3 * (size_t)SZ; }
+  static constexpr size_t lds_elems() { return GF ? (size_t)EXCH + 160 + 2 * (size_t)R * NT : (size_t)EXCH + 160 + 3 * (size_t)SZ; }
+  static constexpr size_t scratch_elems() { return GF ? 3 * (size_t)SZ + 16 : 0; }   // + 16: the transport wave's sink
 };
 
 // Ordered part of the transport step by ONE wave (out of line, see ns2d_fast.hip).  At step t lane l
@@ -97,19 +100,22 @@ __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real*
   }
 }
 
-template <typename real, int NX, int NY, int R, int RW, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int RW, int KIND, bool EQ, int GF>
 __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, const int w, const int b,
                                            const int it_begin, const int it_end, const bool first_chunk,
                                            const bool last_chunk) {
-  using G = Fast2Geom<NX, NY, R>;
+  using G = Fast2Geom<NX, NY, R, GF>;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, LH = G::LH;
   real* exch = reinterpret_cast<real*>(smem);
   real* errp = exch + G::EXCH;   // [2][2][16]: reference norm / unweighted norm partials
   real* sact = errp + 64;        // [64]
   real* red = sact + 64;         // [32]
-  real* Ul = red + 32;
+  real* gscr = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride : nullptr;
+  real* Ul = GF ? gscr : red + 32;
   real* Vl = Ul + SZ;
   real* Tl = Vl + SZ;
+  real* nbl = red + 32;          // GF: Poisson rhs [2 * R][NT]
+  real* sink = GF ? gscr + 3 * SZ : red + 16;   // where the transport wave's masked lanes write
 
   const int tid = threadIdx.x, lane = tid & 63;
   const bool active = lane < LH;
@@ -187,10 +193,10 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   // error weights of this lane's two rows (ghosts copy their interior neighbour)
   const real wl0 = active ? real(1) + (lane == 0 ? 1 : 0) + (top0 ? 1 : 0) : real(0);
   const real wl1 = act1 ? real(1) + (top1 ? 1 : 0) : real(0);
-  const real fW = (active && w == 0) ? real(1) : real(0);
-  const real fE = (active && w == NW - 1) ? real(1) : real(0);
-  // weights of the strip's first / last column (the ghost column next to a wall column counts too)
-  const real cW0 = wl0 * (1 + fW), cW1 = wl1 * (1 + fW), cE0 = wl0 * (1 + fE), cE1 = wl1 * (1 + fE);
+  // weights of the strip's first / last column: a wall column's cells also stand for their ghost copies in the ghost
+  // column (additive: the corner ghosts are never set, rayleigh.py:432-446)
+  const real cW0 = wl0 + ((active && w == 0) ? real(1) : real(0)), cW1 = wl1 + ((act1 && w == 0) ? real(1) : real(0));
+  const real cE0 = wl0 + ((active && w == NW - 1) ? real(1) : real(0)), cE1 = wl1 + ((act1 && w == NW - 1) ? real(1) : real(0));
   const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
 
   int status = 0;
@@ -304,7 +310,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 
     // ---- Poisson rhs from u*, v* in LDS (u*[1,.] = u*[nx+1,.] = v*[.,1] = v*[.,ny+1] = 0 are the
     //      wall values the BC pass left there) ------------------------------------------------
-    real nb[2][RW];
+    real nb[2][GF ? 1 : RW];   // GF: in LDS (NB below)
+#define NB(a, k) (GF ? nbl[((a) * R + (k)) * NT + tid] : nb[a][GF ? 0 : (k)])
 #pragma unroll
     for (int a = 0; a < 2; a++) {
       const int j = j0 + a;
@@ -312,7 +319,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       for (int k = 0; k < RW; k++) {
         const int c = (i0 + k) * SY + j;
         const real div = (Ul[c + SY] - Ul[c]) * rdx + (Vl[c + 1] - Vl[c]) * rdy;
-        nb[a][k] = (a == 0 ? active : act1) ? -A.cb * div : real(0);
+        NB(a, k) = (a == 0 ? active : act1) ? -A.cb * div : real(0);
       }
     }
 
@@ -343,11 +350,11 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       real sn0, sn1;   /* south + north of the lower / upper row */                                  \
       add_pair_neighbours(c0, c1, sn0, sn1);                                                         \
       if (EQ) {                                                                                      \
-        DST[0][K] = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + nb[0][K]);                           \
-        DST[1][K] = cxl1 * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + nb[1][K]);                          \
+        DST[0][K] = cxl * ((EV##0 + WV##0) + sn0) + (cB0 * c0 + NB(0, K));                           \
+        DST[1][K] = cxl1 * ((EV##1 + WV##1) + sn1) + (cB1 * c1 + NB(1, K));                          \
       } else {                                                                                       \
-        DST[0][K] = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + nb[0][K]));                     \
-        DST[1][K] = cxl1 * (EV##1 + WV##1) + (cyl1 * sn1 + (cB1 * c1 + nb[1][K]));                   \
+        DST[0][K] = cxl * (EV##0 + WV##0) + (cyl * sn0 + (cB0 * c0 + NB(0, K)));                     \
+        DST[1][K] = cxl1 * (EV##1 + WV##1) + (cyl1 * sn1 + (cB1 * c1 + NB(1, K)));                   \
       }                                                                                              \
     }
 #define BCN_CELLS(SRC, DST)                                                                          \
@@ -456,6 +463,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #undef BCN_HALO_READS
 #undef BCN_CELLS
 #undef BCN_CELL
+#undef NB
     if (finalB) {
 #pragma unroll
       for (int a = 0; a < 2; a++)
@@ -514,7 +522,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     __syncthreads();
     BCN_PH(4)
     if (w == 0)
-      transport_chain2<real, NX, NY>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+      transport_chain2<real, NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
                                      dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     __syncthreads();
     BCN_PH(5)
@@ -559,50 +567,51 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #endif
 }
 
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 __device__ __forceinline__ void fast2_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
                                            const bool first_chunk, const bool last_chunk, char* smem) {
-  using G = Fast2Geom<NX, NY, R>;
+  using G = Fast2Geom<NX, NY, R, GF>;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (G::RL != R && w == G::NW - 1)
-    fast2_body<real, NX, NY, R, G::RL, KIND, EQ>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
+    fast2_body<real, NX, NY, R, G::RL, KIND, EQ, GF>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
   else
-    fast2_body<real, NX, NY, R, R, KIND, EQ>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
+    fast2_body<real, NX, NY, R, R, KIND, EQ, GF>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
 }
 
 // plain launch: one workgroup per replica, the whole action step
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 __global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_step(NS2DArgs<real> A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
   if (A.mask && !A.mask[b]) return;
-  fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, 0, A.ndt_act, true, true, smem);
+  fast2_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, 0, A.ndt_act, true, true, smem);
 }
 
 // ticketed chunk scheduler (ns2d_sched.h): persistent workgroups draw (chunk, replica) units
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 __global__ __launch_bounds__(((NX + R - 1) / R) * 64) void ns2d_fast2_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch,
                                                                           int nchunk) {
-  using G = Fast2Geom<NX, NY, R>;
+  using G = Fast2Geom<NX, NY, R, GF>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words at the end of the `red` scratch row (block_sum uses red[0..NW), the transport sink red[16..17])
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) + G::EXCH + 128 + 24);
   ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
-    fast2_unit<real, NX, NY, R, KIND, EQ>(A, b, it0, it1, first, last, smem);
+    fast2_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, it0, it1, first, last, smem);
   });
 }
 
-template <typename real, int NX, int NY, int R, int KIND, bool EQ>
+template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
-  using G = Fast2Geom<NX, NY, R>;
+  using G = Fast2Geom<NX, NY, R, GF>;
   const size_t lds = G::lds_elems() * sizeof(real);
+  if (GF && (!a.fscr || a.fscr_stride < G::scratch_elems())) { bcn_set_error("fast2 path: field scratch missing"); return BCN_ERR_UNSUPPORTED; }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
   if (const char* e = getenv("BCN_VERIFY_CONV")) c.verify_conv = atoi(e);
   const SchedParams sp = ns2d_sched_params(a);
   const int q = sp.q_set ? sp.q : 20;   // 100x100: 20 timesteps per chunk measured best (37.7 vs 38.2 ms at 10)
   if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * q && a.sched_ctl) {
-    auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ>;
+    auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ, GF>;
     static unsigned long long set2 = 0;
     if (ns2d_first_on_device(set2)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nchunk = a.ndt_act / q;
@@ -614,7 +623,7 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     return BCN_OK;
   }
   if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
-  auto k = ns2d_fast2_step<real, NX, NY, R, KIND, EQ>;
+  auto k = ns2d_fast2_step<real, NX, NY, R, KIND, EQ, GF>;
   static unsigned long long set = 0;
   if (ns2d_first_on_device(set)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
@@ -623,11 +632,11 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   return BCN_OK;
 }
 
-template <typename real, int NX, int NY, int R, int KIND>
+template <typename real, int NX, int NY, int R, int KIND, int GF = 0>
 int launch_fast2(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   // dx == dy (every reference configuration): one multiply per cell instead of two
-  if (a.cx == a.cy) return launch_fast2_eq<real, NX, NY, R, KIND, true>(a, batch, s);
-  return launch_fast2_eq<real, NX, NY, R, KIND, false>(a, batch, s);
+  if (a.cx == a.cy) return launch_fast2_eq<real, NX, NY, R, KIND, true, GF>(a, batch, s);
+  return launch_fast2_eq<real, NX, NY, R, KIND, false, GF>(a, batch, s);
 }
 
 }  // namespace

@@ -56,14 +56,18 @@ def choose(nx, ny, f64, kind):
                 if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
         return None
-    if ny <= 128 and not f64:
-        for nw, rmax in ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26)):
+    if ny <= 128:
+        # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); mixing only (KIND 1 has no buoyancy
+        # read of S in the predictor that the scratch would slow down further -- and it is the case the reference has)
+        for nw, rmax in (((8, 13),) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
             r = -(-nx // nw)
             rl = nx - (nw - 1) * r
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
                 continue
-            if (2 * nw * 4 * 64 + 160 + 3 * (nx + 2) * (ny + 2)) * esz <= LDS_BYTES:
-                return {"rows": 2, "R": r, "gf": 0, "nw": nw}
+            exch = 2 * nw * 4 * 64 + 160
+            lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
+            if lds <= LDS_BYTES:
+                return {"rows": 2, "R": r, "gf": 1 if f64 else 0, "nw": nw}
     return None
 
 
