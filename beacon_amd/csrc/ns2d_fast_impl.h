@@ -75,7 +75,7 @@ struct FastGeom {
   static constexpr int EXCH = 2 * NW * 2 * 64;              // [2 buffers][NW][west edge | east edge][64]
   static constexpr int MISC = EXCH + 160 + 16;              // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
-  static constexpr int BACK = (NY + PD + 1) * SY;
+  static constexpr int BACK = (NY + 3 * PD + 2) * SY;   // the transport wave prefetches two blocks of PD diagonals ahead
   static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
   static constexpr int MISCA = (MISC + 15) / 16 * 16;
   static constexpr size_t lds_elems() {
@@ -112,6 +112,68 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
       constexpr bool FUSED = std::is_same<real, float>::value && GF == 0;
       if constexpr (FUSED) {   // row 1: explicit part += as * T[i][0] (LDS accesses of one wave are in program order)
         for (int i = 1 + lane; i <= NX; i += 64) Tl[i * SY + 1] += (c0y + c1y * Ul[i * SY + 1 + G::SZ]) * Tl[i * SY];
+      }
+      if constexpr (FUSED) {
+        // Blocks of PD = 4 diagonals, two register sets: a block first requests the next block's explicit parts, u and v
+        // (pairs of diagonals are 66 elements apart: ds_read2_b32, 6 LDS instructions per block), then computes its own
+        // four steps from registers and stores them as two ds_write2_b32 -- 2 LDS instructions per step instead of 4;
+        // the lone wave pays ~16 cycles of issue for each.
+        static_assert(PD == 4, "block of four diagonals");
+        real tp = Tl[0 * SY + j];                        // west ghost
+        real aA[PD], uA[PD], vA[PD], aB[PD], uB[PD], vB[PD];
+#define BCN_LOAD(RA, RU, RV, T0)                                                              \
+        {                                                                                     \
+          const real* const Tq = Tb + (T0) * SY;                                              \
+          const real* const Uq = Ul + cb + (T0) * SY;                                         \
+          const real* const Vq = Uq + G::SZ;   /* V = U + SZ (LDS map) */                     \
+          RA[0] = Tq[0]; RA[1] = Tq[SY]; RA[2] = Tq[2 * SY]; RA[3] = Tq[3 * SY];              \
+          RU[0] = Uq[0]; RU[1] = Uq[SY]; RU[2] = Uq[2 * SY]; RU[3] = Uq[3 * SY];              \
+          RV[0] = Vq[0]; RV[1] = Vq[SY]; RV[2] = Vq[2 * SY]; RV[3] = Vq[3 * SY];              \
+        }
+        // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
+#define BCN_BLOCK(RA, RU, RV, NA, NU, NV, T0, MASK)                                           \
+        {                                                                                     \
+          BCN_LOAD(NA, NU, NV, (T0) + PD)                                                     \
+          real* const Tq = Tb + (T0) * SY;                                                    \
+          real tq[PD];                                                                        \
+          bool okq[PD];                                                                       \
+          _Pragma("unroll") for (int q = 0; q < PD; q++) {                                    \
+            const int t = (T0) + q;                                                           \
+            const float aw = c0x + c1x * RU[q], as = c0y + c1y * RV[q];                       \
+            float t1 = RA[q] + aw * tp;                                                       \
+            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
+                         : "+v"(t1) : "v"(tp), "v"(as));                                      \
+            tq[q] = t1;                                                                       \
+            okq[q] = (MASK == 0) || (active && (MASK != 2 ? (lane <= t) : true) &&            \
+                                     (MASK != 1 ? (lane > t - NX && t < NSTEP) : true));      \
+            tp = okq[q] ? t1 : tp;                                                            \
+          }                                                                                   \
+          if (MASK == 0) {                                                                    \
+            Tq[0] = tq[0]; Tq[SY] = tq[1]; Tq[2 * SY] = tq[2]; Tq[3 * SY] = tq[3];            \
+          } else {                                                                            \
+            _Pragma("unroll") for (int q = 0; q < PD; q++) { real* dst = okq[q] ? Tq + q * SY : dummy; *dst = tq[q]; } \
+          }                                                                                   \
+        }
+#define BCN_CHAIN2(T0, T1, MASK)                                                              \
+        for (int t0 = (T0); t0 < (T1); t0 += 2 * PD) {                                        \
+          BCN_BLOCK(aA, uA, vA, aB, uB, vB, t0, MASK)                                         \
+          BCN_BLOCK(aB, uB, vB, aA, uA, vA, t0 + PD, MASK)                                    \
+        }
+        BCN_LOAD(aA, uA, vA, 0)
+        // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of 2 PD
+        constexpr int P2 = 2 * PD;
+        constexpr int TA2 = ((NY - 1 + P2 - 1) / P2) * P2, TB2 = (NX / P2) * P2, TE2 = ((NSTEP + P2 - 1) / P2) * P2;
+        if constexpr (TA2 <= TB2 && NY == 64) {
+          BCN_CHAIN2(0, TA2, 1)
+          BCN_CHAIN2(TA2, TB2, 0)
+          BCN_CHAIN2(TB2, TE2, 2)
+        } else {
+          BCN_CHAIN2(0, TE2, 3)
+        }
+#undef BCN_CHAIN2
+#undef BCN_BLOCK
+#undef BCN_LOAD
+        return;
       }
       real ra[PD], ru[PD], rv[PD], rg[PD];
 #pragma unroll
