@@ -59,7 +59,7 @@ def choose(nx, ny, f64, kind):
     if ny <= 128:
         # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); mixing only (KIND 1 has no buoyancy
         # read of S in the predictor that the scratch would slow down further -- and it is the case the reference has)
-        for nw, rmax in (((8, 13),) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
+        for nw, rmax in (((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
             r = -(-nx // nw)
             rl = nx - (nw - 1) * r
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
@@ -141,7 +141,7 @@ def plugin_for(nx, ny, f64, kind):
 # they ship with the tree; any other grid compiles at its first use
 TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 64, False, 0), (110, 64, True, 0),
               (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
-              (100, 105, False, 1)]
+              (100, 105, False, 1), (50, 70, True, 0)]
 
 
 def prebuild(grids=None, verbose=False):
