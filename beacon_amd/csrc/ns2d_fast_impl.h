@@ -72,7 +72,10 @@ struct FastGeom {
   // LDS map (elements): [ exchange 2*NW*2*64 | errp 64 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
-  static constexpr int EXCH = 2 * NW * 2 * 64;              // [2 buffers][NW][west edge | east edge][64]
+  // columns per strip in the exchange buffer: 0, 1, R-2, R-1 (depth-2 halos: two sweeps per barrier), or the two edge
+  // columns only where LDS is short (GF == 2: two float64 fields in LDS)
+  static constexpr int XC = (GF == 2) ? 2 : 4;
+  static constexpr int EXCH = 2 * NW * XC * 64;             // [2 buffers][NW][XC][64]
   static constexpr int MISC = EXCH + 160 + 16;              // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + 3 * PD + 2) * SY;   // the transport wave prefetches two blocks of PD diagonals ahead
@@ -260,7 +263,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   real* __restrict__ gv = A.v + off;
   real* __restrict__ gp = A.p + off;
   real* __restrict__ gS = A.S + off;
-  auto ex = [&](int buf, int wave, int which) -> real* { return exch + ((buf * NW + wave) * 2 + which) * 64; };
+  constexpr int XC = G::XC, XL = XC - 1;   // XL: slot of the strip's last column
+  auto ex = [&](int buf, int wave, int which) -> real* { return exch + ((buf * NW + wave) * XC + which) * 64; };
 
   // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
   for (int c = tid; c < SX * SY; c += NT) {
@@ -418,6 +422,17 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         nb[k] = active ? -A.cb * ((ue - us[k]) * rdx + (vn - vs[k]) * rdy) : real(0);
       }
     }
+    // rhs of the neighbouring strips' edge columns: the double sweeps below recompute those columns (depth-2 halos)
+    const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
+    real nbW = 0, nbE = 0;
+    if constexpr (XC == 4) {
+      ex(xb, w, 0)[lane] = nb[0];
+      ex(xb, w, 3)[lane] = nb[R - 1];
+      __syncthreads();
+      nbW = ex(xb, wm, 3)[lane];
+      nbE = ex(xb, wp, 0)[lane];
+      xb ^= 1;
+    }
 
     BCN_PH(1)
     const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
@@ -455,9 +470,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       if (NY < 64) ph *= actf;                            // lanes past the top row stay 0
       return ph;
     };
-    const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
     real hW = 0, hE = 0;            // halos of the array the last sweep read
-    real hWr = 0, hEr = 0;          // halos of the array the last sweep wrote (LDS reads issued behind its barrier)
+    // columns -1, -2 / R, R+1 of the array the last sweep wrote (LDS reads issued behind its barrier)
+    real hW1r = 0, hW2r = 0, hE1r = 0, hE2r = 0;
     int itp = 0;
 #ifdef BCN_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -484,22 +499,53 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       /* keep the halo-dependent part behind the interior cells: hipcc otherwise sometimes hoists the edge cells \
          (and their s_waitcnt on the LDS reads) in front of them: +170 cycles per sweep */   \
       __builtin_amdgcn_sched_barrier(0);                                                     \
-      hW = (w > 0) ? hWr : SRC[0];                                                           \
-      hE = (w < NW - 1) ? hEr : SRC[R - 1];                                                  \
+      hW = (w > 0) ? hW1r : SRC[0];                                                          \
+      hE = (w < NW - 1) ? hE1r : SRC[R - 1];                                                 \
       const real p0 = cell(SRC[0], SRC[1], hW, nb[0]);                                       \
       const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
       DST[0] = p0;                                                                           \
       DST[R - 1] = pl;                                                                       \
-      ex(xb, w, 0)[lane] = p0;                                                               \
-      ex(xb, w, 1)[lane] = pl;
+      BCN_PUBLISH(DST)
+#define BCN_PUBLISH(DST)                                                                     \
+      ex(xb, w, 0)[lane] = DST[0];                                                           \
+      ex(xb, w, XL)[lane] = DST[R - 1];                                                      \
+      if constexpr (XC == 4) { ex(xb, w, 1)[lane] = DST[1]; ex(xb, w, 2)[lane] = DST[R - 2]; }
+#define BCN_HALO_READS                                                                       \
+      hW1r = ex(xb, wm, XL)[lane];                                                           \
+      hE1r = ex(xb, wp, 0)[lane];                                                            \
+      if constexpr (XC == 4) { hW2r = ex(xb, wm, 2)[lane]; hE2r = ex(xb, wp, 1)[lane]; }     \
+      xb ^= 1;
 #define BCN_SWEEP_END                                                                        \
       __syncthreads();                                                                       \
       itp++;                                                                                 \
-      hWr = ex(xb, wm, 1)[lane];                                                             \
-      hEr = ex(xb, wp, 0)[lane];                                                             \
-      xb ^= 1;
+      BCN_HALO_READS
     // a sweep that does not evaluate the residual
 #define BCN_FAST(SRC, DST) { BCN_CELLS(SRC, DST) BCN_SWEEP_END }
+    // TWO such sweeps (X -> Y -> X) behind ONE barrier: the first also advances the neighbours' edge columns -1 and R from
+    // the depth-2 halos (a wall's ghost column mirrors the strip's own new edge), the second then needs nothing from other
+    // waves.  Two redundant cells per 2 R, half the barriers and exchanges; every value is computed exactly as in two
+    // single sweeps.
+#define BCN_FAST2X(X, Y)                                                                     \
+    {                                                                                        \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) Y[k] = cell(X[k], X[k + 1], X[k - 1], nb[k]); \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      const real xw1 = (w > 0) ? hW1r : X[0], xe1 = (w < NW - 1) ? hE1r : X[R - 1];          \
+      Y[0] = cell(X[0], X[1], xw1, nb[0]);                                                   \
+      Y[R - 1] = cell(X[R - 1], xe1, X[R - 2], nb[R - 1]);                                   \
+      real yw = cell(hW1r, X[0], hW2r, nbW), ye = cell(hE1r, hE2r, X[R - 1], nbE);           \
+      yw = (w > 0) ? yw : Y[0];                                                              \
+      ye = (w < NW - 1) ? ye : Y[R - 1];                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) X[k] = cell(Y[k], Y[k + 1], Y[k - 1], nb[k]); \
+      const real x0 = cell(Y[0], Y[1], yw, nb[0]), xl = cell(Y[R - 1], ye, Y[R - 2], nb[R - 1]); \
+      X[0] = x0;                                                                             \
+      X[R - 1] = xl;                                                                         \
+      hW = yw; hE = ye;                                                                      \
+      BCN_PUBLISH(X)                                                                         \
+      __syncthreads();                                                                       \
+      itp += 2;                                                                              \
+      BCN_HALO_READS                                                                         \
+    }
     // a sweep that does (the same arithmetic, in the same order, as when it was fused into the cells), evaluated right
     // behind its barrier; sets `n`: the number of following sweeps that cannot pass the test
 #define BCN_CHECK(SRC, DST, DST_IS_B)                                                        \
@@ -523,9 +569,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 32 + q];              \
       if (A.conv_plan == 1) { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = errp[xb * 32 + 16 + q]; } \
       else { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = 0; }                     \
-      hWr = ex(xb, wm, 1)[lane];                                                             \
-      hEr = ex(xb, wp, 0)[lane];                                                             \
-      xb ^= 1;                                                                               \
+      BCN_HALO_READS                                                                         \
       /* every lane sums the NW partials it read by broadcast, in a fixed order: uniform */  \
       _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                   \
         _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st];     \
@@ -576,12 +620,19 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         n = (n - 1) & ~1;
       }
       if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
-      for (; n > 0; n -= 2) {
-        BCN_FAST(phA, phB)
-        BCN_FAST(phB, phA)
+      if constexpr (XC == 4) {
+        for (; n > 0; n -= 2) BCN_FAST2X(phA, phB)
+      } else {
+        for (; n > 0; n -= 2) {
+          BCN_FAST(phA, phB)
+          BCN_FAST(phB, phA)
+        }
       }
     }
 #undef BCN_CHECK
+#undef BCN_FAST2X
+#undef BCN_HALO_READS
+#undef BCN_PUBLISH
 #undef BCN_FAST
 #undef BCN_SWEEP_END
 #undef BCN_CELLS
@@ -589,7 +640,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #pragma unroll
       for (int k = 0; k < R; k++) phA[k] = phB[k];
     }
-    hW = hWr;   // west halo of the final phi (read behind the last barrier; unused by wave 0)
+    hW = hW1r;   // west halo of the final phi (read behind the last barrier; unused by wave 0)
 #ifdef BCN_STAMP   // diagnostic build only: cycles per sweep in the high half of the sweep count
     {
       const unsigned long long st1 = __builtin_amdgcn_s_memtime();
