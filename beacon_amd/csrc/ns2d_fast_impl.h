@@ -89,153 +89,145 @@ struct FastGeom {
   }
 };
 
-// Ordered part of the transport step, run by ONE wave (kept out of line: its unrolled,
-// software-pipelined loops would otherwise inflate the register pressure of the whole kernel).
+// Ordered part of the transport step, run by ONE wave (kept out of line: its unrolled, software-pipelined loops would
+// otherwise inflate the register pressure of the whole kernel).  At step t lane l works on cell (i, j) = (t - l + 1, l + 1),
+// element cb + t*SY of the [i][j] arrays: S' = A + aW S'(i-1,j) + aS S'(i,j-1) with the west value in a register and the
+// south value from the lane below by DPP.  Reads are unmasked (see the LDS map), only writes are.
+//
+// float32 with the fields in LDS (GF == 0): the south term is ONE v_fmac_f32_dpp -- tn = (A + aW tp) + aS * tp(lane-1);
+// lane 0 has no lane below and keeps the first sum: its south value is the ghost row T[i][0], which the chain never
+// updates, so its term is folded into A beforehand.  Blocks of four diagonals with two register sets: a block first
+// requests the next block's A, u, v (two diagonals are SY elements apart: ds_read2_b32; V starts SZ elements behind U),
+// then computes its four steps from registers and stores them pairwise.  A lone wave issues one instruction per ~4.6
+// cycles whatever its kind: 14 -> 10 instructions per steady step; the ragged first and last thirds of the sweep carry three
+// mask instructions more.
+template <int NX, int NY, int R>
+__device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const float* Ul, float* dummy, float c0x, float c1x,
+                                                              float c0y, float c1y) {
+  using G = FastGeom<NX, NY, R, 0>;
+  constexpr int SY = G::SY, PD = G::PD, NSTEP = NX + NY - 1;
+  static_assert(PD == 4, "block of four diagonals");
+  const int lane = threadIdx.x & 63;
+  const int j = lane + 1;
+  const bool active = lane < NY;
+  const int cb = (1 - lane) * SY + j;
+  float* Tb = Tl + cb;
+  // row 1: A += aS * T[i][0] (LDS accesses of one wave are in program order)
+  for (int i = 1 + lane; i <= NX; i += 64) Tl[i * SY + 1] += (c0y + c1y * Ul[i * SY + 1 + G::SZ]) * Tl[i * SY];
+  float tp = Tl[0 * SY + j];                        // west ghost
+  float aA[PD], uA[PD], vA[PD], aB[PD], uB[PD], vB[PD];
+#define BCN_LOAD(RA, RU, RV, T0)                                                              \
+  {                                                                                           \
+    const float* const Tq = Tb + (T0) * SY;                                                   \
+    const float* const Uq = Ul + cb + (T0) * SY;                                              \
+    const float* const Vq = Uq + G::SZ;                                                       \
+    RA[0] = Tq[0]; RA[1] = Tq[SY]; RA[2] = Tq[2 * SY]; RA[3] = Tq[3 * SY];                    \
+    RU[0] = Uq[0]; RU[1] = Uq[SY]; RU[2] = Uq[2 * SY]; RU[3] = Uq[3 * SY];                    \
+    RV[0] = Vq[0]; RV[1] = Vq[SY]; RV[2] = Vq[2 * SY]; RV[3] = Vq[3 * SY];                    \
+  }
+  // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
+#define BCN_BLOCK(RA, RU, RV, NA, NU, NV, T0, MASK)                                           \
+  {                                                                                           \
+    BCN_LOAD(NA, NU, NV, (T0) + PD)                                                           \
+    float* const Tq = Tb + (T0) * SY;                                                         \
+    float tq[PD];                                                                             \
+    bool okq[PD];                                                                             \
+    _Pragma("unroll") for (int q = 0; q < PD; q++) {                                          \
+      const int t = (T0) + q;                                                                 \
+      const float aw = c0x + c1x * RU[q], as = c0y + c1y * RV[q];                             \
+      float t1 = RA[q] + aw * tp;                                                             \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
+                   : "+v"(t1) : "v"(tp), "v"(as));                                            \
+      tq[q] = t1;                                                                             \
+      okq[q] = (MASK == 0) || (active && (MASK != 2 ? (lane <= t) : true) &&                  \
+                               (MASK != 1 ? (lane > t - NX && t < NSTEP) : true));            \
+      tp = okq[q] ? t1 : tp;                                                                  \
+    }                                                                                         \
+    if (MASK == 0) {                                                                          \
+      Tq[0] = tq[0]; Tq[SY] = tq[1]; Tq[2 * SY] = tq[2]; Tq[3 * SY] = tq[3];                  \
+    } else {                                                                                  \
+      _Pragma("unroll") for (int q = 0; q < PD; q++) { float* dst = okq[q] ? Tq + q * SY : dummy; *dst = tq[q]; } \
+    }                                                                                         \
+  }
+#define BCN_CHAIN2(T0, T1, MASK)                                                              \
+  for (int t0 = (T0); t0 < (T1); t0 += 2 * PD) {                                              \
+    BCN_BLOCK(aA, uA, vA, aB, uB, vB, t0, MASK)                                               \
+    BCN_BLOCK(aB, uB, vB, aA, uA, vA, t0 + PD, MASK)                                          \
+  }
+  BCN_LOAD(aA, uA, vA, 0)
+  // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of 2 PD
+  constexpr int P2 = 2 * PD;
+  constexpr int TA2 = ((NY - 1 + P2 - 1) / P2) * P2, TB2 = (NX / P2) * P2, TE2 = ((NSTEP + P2 - 1) / P2) * P2;
+  if constexpr (TA2 <= TB2 && NY == 64) {
+    BCN_CHAIN2(0, TA2, 1)
+    BCN_CHAIN2(TA2, TB2, 0)
+    BCN_CHAIN2(TB2, TE2, 2)
+  } else {
+    BCN_CHAIN2(0, TE2, 3)
+  }
+#undef BCN_CHAIN2
+#undef BCN_BLOCK
+#undef BCN_LOAD
+}
+
+// The same for float64 and for fields in the global scratch (GF): plain form -- the south value by a DPP move (lane 0:
+// the prefetched ghost element just below its cell), diagonals prefetched PD steps ahead one by one.
 template <typename real, int NX, int NY, int R, int GF>
 __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* Ul, const real* Vl, real* dummy,
                                                           real c0x, real c1x, real c0y, real c1y) {
   using G = FastGeom<NX, NY, R, GF>;
-  constexpr int SY = G::SY, PD = G::PD;
+  constexpr int SY = G::SY, PD = G::PD, NSTEP = NX + NY - 1;
   const int lane = threadIdx.x & 63;
   const int j = lane + 1;
   const bool active = lane < NY;
-      constexpr int NSTEP = NX + NY - 1;
-      // At step t this lane works on cell (i, j) = (t - lane + 1, lane + 1), index cb + t*SY.  The
-      // element just below it, index - 1, is the south ghost T[i][0] for lane 0 (never written
-      // here, so it can be prefetched); the other lanes take their south value from the lane
-      // below by DPP and ignore it.  Reads are unmasked (see the LDS map), only writes are.
-      const int cb = (1 - lane) * SY + j;
-      real* Tb = Tl + cb;
-      // u, v without pads (GF == 2): lanes outside the domain read a clamped index (their values are masked)
-      auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ul[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ul[x]; };
-      auto ldv = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Vl[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Vl[x]; };
-      // FUSED (float32, fields in LDS): the south term is ONE v_fmac_f32_dpp -- tn = (ra + aw tp) + as * tp(lane-1), lane 0
-      // keeps the first sum (its south value is the ghost row, which the explicit part has already folded into ra) --
-      // and u, v come from the same base address (V starts SZ elements behind U): 8 instructions per step instead of 14.
-      constexpr bool FUSED = std::is_same<real, float>::value && GF == 0;
-      if constexpr (FUSED) {   // row 1: explicit part += as * T[i][0] (LDS accesses of one wave are in program order)
-        for (int i = 1 + lane; i <= NX; i += 64) Tl[i * SY + 1] += (c0y + c1y * Ul[i * SY + 1 + G::SZ]) * Tl[i * SY];
-      }
-      if constexpr (FUSED) {
-        // Blocks of PD = 4 diagonals, two register sets: a block first requests the next block's explicit parts, u and v
-        // (pairs of diagonals are 66 elements apart: ds_read2_b32, 6 LDS instructions per block), then computes its own
-        // four steps from registers and stores them as two ds_write2_b32 -- 2 LDS instructions per step instead of 4;
-        // the lone wave pays ~16 cycles of issue for each.
-        static_assert(PD == 4, "block of four diagonals");
-        real tp = Tl[0 * SY + j];                        // west ghost
-        real aA[PD], uA[PD], vA[PD], aB[PD], uB[PD], vB[PD];
-#define BCN_LOAD(RA, RU, RV, T0)                                                              \
-        {                                                                                     \
-          const real* const Tq = Tb + (T0) * SY;                                              \
-          const real* const Uq = Ul + cb + (T0) * SY;                                         \
-          const real* const Vq = Uq + G::SZ;   /* V = U + SZ (LDS map) */                     \
-          RA[0] = Tq[0]; RA[1] = Tq[SY]; RA[2] = Tq[2 * SY]; RA[3] = Tq[3 * SY];              \
-          RU[0] = Uq[0]; RU[1] = Uq[SY]; RU[2] = Uq[2 * SY]; RU[3] = Uq[3 * SY];              \
-          RV[0] = Vq[0]; RV[1] = Vq[SY]; RV[2] = Vq[2 * SY]; RV[3] = Vq[3 * SY];              \
-        }
-        // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
-#define BCN_BLOCK(RA, RU, RV, NA, NU, NV, T0, MASK)                                           \
-        {                                                                                     \
-          BCN_LOAD(NA, NU, NV, (T0) + PD)                                                     \
-          real* const Tq = Tb + (T0) * SY;                                                    \
-          real tq[PD];                                                                        \
-          bool okq[PD];                                                                       \
-          _Pragma("unroll") for (int q = 0; q < PD; q++) {                                    \
-            const int t = (T0) + q;                                                           \
-            const float aw = c0x + c1x * RU[q], as = c0y + c1y * RV[q];                       \
-            float t1 = RA[q] + aw * tp;                                                       \
-            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
-                         : "+v"(t1) : "v"(tp), "v"(as));                                      \
-            tq[q] = t1;                                                                       \
-            okq[q] = (MASK == 0) || (active && (MASK != 2 ? (lane <= t) : true) &&            \
-                                     (MASK != 1 ? (lane > t - NX && t < NSTEP) : true));      \
-            tp = okq[q] ? t1 : tp;                                                            \
-          }                                                                                   \
-          if (MASK == 0) {                                                                    \
-            Tq[0] = tq[0]; Tq[SY] = tq[1]; Tq[2 * SY] = tq[2]; Tq[3 * SY] = tq[3];            \
-          } else {                                                                            \
-            _Pragma("unroll") for (int q = 0; q < PD; q++) { real* dst = okq[q] ? Tq + q * SY : dummy; *dst = tq[q]; } \
-          }                                                                                   \
-        }
-#define BCN_CHAIN2(T0, T1, MASK)                                                              \
-        for (int t0 = (T0); t0 < (T1); t0 += 2 * PD) {                                        \
-          BCN_BLOCK(aA, uA, vA, aB, uB, vB, t0, MASK)                                         \
-          BCN_BLOCK(aB, uB, vB, aA, uA, vA, t0 + PD, MASK)                                    \
-        }
-        BCN_LOAD(aA, uA, vA, 0)
-        // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of 2 PD
-        constexpr int P2 = 2 * PD;
-        constexpr int TA2 = ((NY - 1 + P2 - 1) / P2) * P2, TB2 = (NX / P2) * P2, TE2 = ((NSTEP + P2 - 1) / P2) * P2;
-        if constexpr (TA2 <= TB2 && NY == 64) {
-          BCN_CHAIN2(0, TA2, 1)
-          BCN_CHAIN2(TA2, TB2, 0)
-          BCN_CHAIN2(TB2, TE2, 2)
-        } else {
-          BCN_CHAIN2(0, TE2, 3)
-        }
-#undef BCN_CHAIN2
-#undef BCN_BLOCK
-#undef BCN_LOAD
-        return;
-      }
-      real ra[PD], ru[PD], rv[PD], rg[PD];
+  const int cb = (1 - lane) * SY + j;
+  real* Tb = Tl + cb;
+  // u, v without pads (GF == 2): lanes outside the domain read a clamped index (their values are masked)
+  auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ul[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ul[x]; };
+  auto ldv = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Vl[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Vl[x]; };
+  real ra[PD], ru[PD], rv[PD], rg[PD];
 #pragma unroll
-      for (int q = 0; q < PD; q++) {
-        ra[q] = Tb[q * SY];
-        if (FUSED) { ru[q] = Ul[cb + q * SY]; rv[q] = Ul[cb + q * SY + G::SZ]; rg[q] = 0; }   // V = U + SZ (LDS map)
-        else { ru[q] = ldu(q); rv[q] = ldv(q); rg[q] = Tb[q * SY - 1]; }
-      }
-      real tp = Tl[0 * SY + j];                        // west ghost
-      // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
+  for (int q = 0; q < PD; q++) { ra[q] = Tb[q * SY]; ru[q] = ldu(q); rv[q] = ldv(q); rg[q] = Tb[q * SY - 1]; }
+  real tp = Tl[0 * SY + j];                        // west ghost
+  // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
 #define BCN_CHAIN(T0, T1, MASK)                                                             \
-      for (int t0 = (T0); t0 < (T1); t0 += PD) {                                            \
-        /* one running address per array and block of PD steps: the steps use immediate offsets */ \
-        real* const Tq = Tb + t0 * SY;                                                      \
-        const real* const Uq = Ul + cb + t0 * SY;                                           \
-        const real* const Vq = Uq + G::SZ;                                                  \
-        _Pragma("unroll") for (int q = 0; q < PD; q++) {                                    \
-          const int t = t0 + q;                                                             \
-          const real aw = c0x + c1x * ru[q], as = c0y + c1y * rv[q];                        \
-          real tn;                                                                          \
-          if constexpr (FUSED) {                                                            \
-            float t1 = ra[q] + aw * tp;                                                     \
-            asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
-                         : "+v"(t1) : "v"(tp), "v"(as));                                    \
-            tn = t1;                                                                        \
-          } else {                                                                          \
-            const real s = from_below(rg[q], tp);                                           \
-            tn = ra[q] + aw * tp + as * s;                                                  \
-          }                                                                                 \
-          if (MASK == 0) {                                                                  \
-            tp = tn;                                                                        \
-            Tq[q * SY] = tn;                                                                \
-          } else {                                                                          \
-            const bool ok = active && (MASK != 2 ? (lane <= t) : true) &&                   \
-                            (MASK != 1 ? (lane > t - NX && t < NSTEP) : true);              \
-            tp = ok ? tn : tp;                                                              \
-            real* dst = ok ? Tq + q * SY : dummy;                                           \
-            *dst = tn;                                                                      \
-          }                                                                                 \
-          ra[q] = Tq[(q + PD) * SY];                                                        \
-          if (FUSED) { ru[q] = Uq[(q + PD) * SY]; rv[q] = Vq[(q + PD) * SY]; }              \
-          else { ru[q] = ldu(t + PD); rv[q] = ldv(t + PD); rg[q] = Tq[(q + PD) * SY - 1]; } \
-        }                                                                                   \
-      }
-      // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of PD
-      constexpr int TA = ((NY - 1 + PD - 1) / PD) * PD;      // first steady step (rounded up)
-      constexpr int TB = (NX / PD) * PD;                      // end of the steady phase (rounded down)
-      if constexpr (TA <= TB) {
-        BCN_CHAIN(0, TA, 1)
-        if (NY == 64) { BCN_CHAIN(TA, TB, 0) } else { BCN_CHAIN(TA, TB, 1) }
-        BCN_CHAIN(TB, NSTEP, 2)
-      } else {                                               // (nearly) square grid: no steady phase
-        constexpr int TL = ((NY - 1) / PD) * PD, TH = ((NX + PD - 1) / PD) * PD;
-        BCN_CHAIN(0, TL, 1)
-        BCN_CHAIN(TL, TH, 3)
-        BCN_CHAIN(TH, NSTEP, 2)
-      }
+  for (int t0 = (T0); t0 < (T1); t0 += PD) {                                                \
+    _Pragma("unroll") for (int q = 0; q < PD; q++) {                                        \
+      const int t = t0 + q;                                                                 \
+      const real s = from_below(rg[q], tp);                                                 \
+      const real aw = c0x + c1x * ru[q], as = c0y + c1y * rv[q];                            \
+      const real tn = ra[q] + aw * tp + as * s;                                             \
+      if (MASK == 0) {                                                                      \
+        tp = tn;                                                                            \
+        Tb[t * SY] = tn;                                                                    \
+      } else {                                                                              \
+        const bool ok = active && (MASK != 2 ? (lane <= t) : true) &&                       \
+                        (MASK != 1 ? (lane > t - NX && t < NSTEP) : true);                  \
+        tp = ok ? tn : tp;                                                                  \
+        real* dst = ok ? Tb + t * SY : dummy;                                               \
+        *dst = tn;                                                                          \
+      }                                                                                     \
+      ra[q] = Tb[(t + PD) * SY];                                                            \
+      ru[q] = ldu(t + PD);                                                                  \
+      rv[q] = ldv(t + PD);                                                                  \
+      rg[q] = Tb[(t + PD) * SY - 1];                                                        \
+    }                                                                                       \
+  }
+  // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of PD
+  constexpr int TA = ((NY - 1 + PD - 1) / PD) * PD;      // first steady step (rounded up)
+  constexpr int TB = (NX / PD) * PD;                      // end of the steady phase (rounded down)
+  if constexpr (TA <= TB) {
+    BCN_CHAIN(0, TA, 1)
+    if (NY == 64) { BCN_CHAIN(TA, TB, 0) } else { BCN_CHAIN(TA, TB, 1) }
+    BCN_CHAIN(TB, NSTEP, 2)
+  } else {                                               // (nearly) square grid: no steady phase
+    constexpr int TL = ((NY - 1) / PD) * PD, TH = ((NX + PD - 1) / PD) * PD;
+    BCN_CHAIN(0, TL, 1)
+    BCN_CHAIN(TL, TH, 3)
+    BCN_CHAIN(TH, NSTEP, 2)
+  }
 #undef BCN_CHAIN
-    }
+}
 
 // One unit of work: timesteps [it_begin, it_end) of replica b (state HBM -> chip -> HBM).
 // R0: columns of a full strip (the geometry), R = RW: columns of THIS wave's strip (R0, or RL for the last wave)
@@ -695,8 +687,12 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     BCN_PH(4)
     // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
     if (w == 0) {
-      transport_chain<real, NX, NY, R0, GF>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
-                                       dt * A.ksc * rdy2, real(0.5) * dt * rdy);
+      if constexpr (std::is_same<real, float>::value && GF == 0)
+        transport_chain_f32<NX, NY, R0>(Tl, Ul, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2,
+                                        real(0.5) * dt * rdy);
+      else
+        transport_chain<real, NX, NY, R0, GF>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+                                              dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     }
     __syncthreads();
     BCN_PH(5)
