@@ -555,17 +555,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + dl * dl);                  \
         if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                     \
       }                                                                                      \
-      real eB[NW], eU[NW];                                                                   \
       __syncthreads();                                                                       \
       itp++;                                                                                 \
-      _Pragma("unroll") for (int q = 0; q < NW; q++) eB[q] = errp[xb * 32 + q];              \
-      if (A.conv_plan == 1) { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = errp[xb * 32 + 16 + q]; } \
-      else { _Pragma("unroll") for (int q = 0; q < NW; q++) eU[q] = 0; }                     \
+      /* one read: lane q holds wave q's partial of the reference norm, lane 16 + q that of the unweighted norm; \
+         summed in a fixed order, uniformly in every lane */                                 \
+      const real epart = errp[xb * 32 + (lane & 31)];                                        \
       BCN_HALO_READS                                                                         \
-      /* every lane sums the NW partials it read by broadcast, in a fixed order: uniform */  \
-      _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                                   \
-        _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eB[q] += eB[q + st];     \
-      const real err = read_lane(eB[0], 0);                                                  \
+      const real esum = row16_sum<real>(epart);                                              \
+      const real err = read_lane(esum, 15);                                                  \
       if (!(err > A.tol)) {                                                                  \
         if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
         finalB = DST_IS_B; break;                                                            \
@@ -575,12 +572,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       if (skip_left > 0) {                                                                   \
         skip_left--;                                                                         \
       } else if (A.conv_plan > 0) {   /* plan the next evaluation (see above) */             \
-        float l2u = 0;                                                                       \
-        if (A.conv_plan == 1) {                                                              \
-          _Pragma("unroll") for (int st = 1; st < NW; st *= 2)                               \
-            _Pragma("unroll") for (int q = 0; q + st < NW; q += 2 * st) eU[q] += eU[q + st]; \
-          l2u = __log2f((float)read_lane(eU[0], 0));                                         \
-        }                                                                                    \
+        const float l2u = (A.conv_plan == 1) ? __log2f((float)read_lane(esum, 31)) : 0.f; \
         const float l2w = __log2f((float)err);                                               \
         int j = 0;                                                                           \
         if (k_prev >= 0) {                                                                   \
