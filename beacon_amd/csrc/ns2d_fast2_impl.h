@@ -100,6 +100,83 @@ __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real*
   }
 }
 
+// float32 with the fields in LDS (GF == 0): the same recurrence with the instruction count of the lone wave cut (it
+// issues one instruction per ~4.6 cycles whatever its kind).  The south ghost row's term of row 1 is folded into A
+// beforehand, so that lane 0 needs nothing from below and the south term of the lower row is ONE v_fmac_f32_dpp (a lane
+// without a valid source lane keeps its first sum); the two rows of a column are adjacent in LDS (one paired access for
+// A, u, v and for the result); blocks of four steps with two register sets, a block first requesting the next block's
+// operands.  The control flow stays uniform (EXEC-masked steps made hipcc wait for every LDS operation in flight at each
+// step): lanes in front of / behind the domain read a clamped address, keep their west values and write to `dummy`.
+template <int NX, int NY>
+__device__ __attribute__((noinline)) void transport_chain2_f32(float* Tl, const float* Ul, const float* Vl, float* dummy,
+                                                               float c0x, float c1x, float c0y, float c1y) {
+  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2, PD = 4, NSTEP = NX + LH - 1;
+  constexpr bool ODD = (NY & 1) != 0;
+  const int lane = threadIdx.x & 63;
+  // row 1: A += aS * S[i][0] (LDS accesses of one wave are in program order)
+  for (int i = 1 + lane; i <= NX; i += 64) Tl[i * SY + 1] += (c0y + c1y * Vl[i * SY + 1]) * Tl[i * SY];
+  if (lane >= LH) return;
+  const int cb = (1 - lane) * SY + 2 * lane + 1;     // index of (i, 2l+1) at step t: cb + t*SY
+  float tp0 = Tl[2 * lane + 1], tp1 = Tl[2 * lane + 2];   // west ghosts (column 0)
+  float aA[2 * PD], uA[2 * PD], vA[2 * PD], aB[2 * PD], uB[2 * PD], vB[2 * PD];
+  // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
+#define BCN_LOAD2(RA, RU, RV, T0, MASK)                                                       \
+  _Pragma("unroll") for (int q = 0; q < PD; q++) {                                            \
+    int x = cb + ((T0) + q) * SY;                                                             \
+    if (MASK & 1) x = x < 1 ? 1 : x;                                                          \
+    if (MASK & 2) x = x > SZ - 2 ? SZ - 2 : x;                                                \
+    RA[2 * q] = Tl[x]; RA[2 * q + 1] = Tl[x + 1];                                             \
+    RU[2 * q] = Ul[x]; RU[2 * q + 1] = Ul[x + 1];                                             \
+    RV[2 * q] = Vl[x]; RV[2 * q + 1] = Vl[x + 1];                                             \
+  }
+#define BCN_BLOCK2(RA, RU, RV, NA, NU, NV, T0, MASK, NMASK)                                   \
+  {                                                                                           \
+    BCN_LOAD2(NA, NU, NV, (T0) + PD, NMASK)                                                   \
+    _Pragma("unroll") for (int q = 0; q < PD; q++) {                                          \
+      const int t = (T0) + q;                                                                 \
+      const float aw0 = c0x + c1x * RU[2 * q], as0 = c0y + c1y * RV[2 * q];                   \
+      const float aw1 = c0x + c1x * RU[2 * q + 1], as1 = c0y + c1y * RV[2 * q + 1];           \
+      float t0 = RA[2 * q] + aw0 * tp0;                                                       \
+      asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"        \
+          : "+v"(t0) : "v"(tp1), "v"(as0));                                                   \
+      float t1 = RA[2 * q + 1] + aw1 * tp1;                                                   \
+      t1 += as1 * t0;                                                                         \
+      float* Tq = Tl + (cb + t * SY);                                                         \
+      if (MASK != 0) {                                                                        \
+        const bool ok = (!(MASK & 1) || lane <= t) && (!(MASK & 2) || lane > t - NX);         \
+        tp0 = ok ? t0 : tp0;                                                                  \
+        tp1 = ok ? t1 : tp1;                                                                  \
+        Tq = ok ? Tq : dummy;                                                                 \
+      } else {                                                                                \
+        tp0 = t0; tp1 = t1;                                                                   \
+      }                                                                                       \
+      if (ODD) { Tq[0] = t0; float* Th = (lane < LH - 1) ? Tq : dummy; Th[1] = t1; }   /* odd ny: the last lane has no upper row */ \
+      else { Tq[0] = t0; Tq[1] = t1; }                                                        \
+    }                                                                                         \
+  }
+#define BCN_CHAIN2X(T0, T1, MASK, LASTMASK)                                                   \
+  for (int t0 = (T0); t0 < (T1); t0 += 2 * PD) {                                              \
+    BCN_BLOCK2(aA, uA, vA, aB, uB, vB, t0, MASK, MASK)                                        \
+    if (t0 + 2 * PD < (T1)) BCN_BLOCK2(aB, uB, vB, aA, uA, vA, t0 + PD, MASK, MASK)           \
+    else BCN_BLOCK2(aB, uB, vB, aA, uA, vA, t0 + PD, MASK, LASTMASK)                          \
+  }
+  // lanes 0..LH-1 are all inside the domain for t in [LH-1, NX); phase bounds are multiples of 2 PD.  The last block of
+  // a phase prefetches the first block of the next one: with that phase's clamp.
+  constexpr int P2 = 2 * PD;
+  constexpr int TA2 = ((LH - 1 + P2 - 1) / P2) * P2, TB2 = (NX / P2) * P2, TE2 = ((NSTEP + P2 - 1) / P2) * P2;
+  BCN_LOAD2(aA, uA, vA, 0, 1)
+  if constexpr (TA2 <= TB2) {
+    BCN_CHAIN2X(0, TA2, 1, 0)
+    BCN_CHAIN2X(TA2, TB2, 0, 2)
+    BCN_CHAIN2X(TB2, TE2, 2, 2)
+  } else {
+    BCN_CHAIN2X(0, TE2, 3, 3)
+  }
+#undef BCN_CHAIN2X
+#undef BCN_BLOCK2
+#undef BCN_LOAD2
+}
+
 template <typename real, int NX, int NY, int R, int RW, int KIND, bool EQ, int GF>
 __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, const int w, const int b,
                                            const int it_begin, const int it_end, const bool first_chunk,
@@ -521,9 +598,13 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     }
     __syncthreads();
     BCN_PH(4)
-    if (w == 0)
-      transport_chain2<real, NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
-                                     dt * A.ksc * rdy2, real(0.5) * dt * rdy);
+    if (w == 0) {
+      if constexpr (std::is_same<real, float>::value && GF == 0)
+        transport_chain2_f32<NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2, real(0.5) * dt * rdy);
+      else
+        transport_chain2<real, NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+                                       dt * A.ksc * rdy2, real(0.5) * dt * rdy);
+    }
     __syncthreads();
     BCN_PH(5)
   }

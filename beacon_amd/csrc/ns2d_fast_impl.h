@@ -741,9 +741,15 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
   else fast_body<real, NX, NY, R, R, KIND, EQ, GF>(A, w, b, it_begin, it_end, first_chunk, last_chunk, smem);
 }
 
+#ifdef BCN_JIT_WPE   // experiment: cap the registers so that BCN_JIT_WPE waves fit a SIMD (two workgroups per CU)
+#define BCN_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(BCN_JIT_WPE, BCN_JIT_WPE)))
+#else
+#define BCN_KERNEL_ATTR
+#endif
+
 // plain launch: one workgroup per replica, timesteps [A.it_begin, A.it_end)
 template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__global__ __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_step(NS2DArgs<real> A) {
+__global__ BCN_KERNEL_ATTR __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_step(NS2DArgs<real> A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
   if (A.mask && !A.mask[b]) return;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_step(
 
 // ---- ticketed chunk scheduler (ns2d_sched.h) ---------------------------------------------------
 template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__global__ __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
+__global__ BCN_KERNEL_ATTR __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_body's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +

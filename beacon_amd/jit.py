@@ -88,7 +88,9 @@ def build_plugin(nx, ny, f64, kind, verbose=False):
     if m is None or os.environ.get("BEACON_JIT", "1") == "0":
         return None
     defs = {"BCN_JIT_ROWS": m["rows"], "BCN_JIT_REAL": "double" if f64 else "float", "BCN_JIT_NX": nx, "BCN_JIT_NY": ny,
-            "BCN_JIT_R": m["R"], "BCN_JIT_KIND": kind, "BCN_JIT_GF": m["gf"]}
+            "BCN_JIT_R": m["R"], "BCN_JIT_KIND": kind, "BCN_JIT_GF": int(os.environ.get("BEACON_JIT_GF", m["gf"]))}
+    if os.environ.get("BEACON_JIT_WPE"):              # experiment: waves per SIMD the register allocation must allow
+        defs["BCN_JIT_WPE"] = int(os.environ["BEACON_JIT_WPE"])
     name = "ns2d_%dx%d_%s_k%d_r%d_%s.so" % (nx, ny, "f64" if f64 else "f32", kind, m["R"], _signature(defs))
     path = os.path.join(JIT_DIR, name)
     if os.path.exists(path):

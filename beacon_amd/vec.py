@@ -6,6 +6,7 @@ provider -- all arithmetic happens in libbeacon_hip.so).
 Derived parameters are computed exactly as the reference constructors do (citations are
 file:line into /root/reference/beacon/)."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -161,7 +162,7 @@ class VecEnv(object):
     def _attach_plugin(self, kind):
         """2D envs: a grid without a built-in register-resident kernel gets one compiled for it (beacon_amd/jit.py);
         when that is not possible the generic kernel stays selected."""
-        if self.lib.bcn_set_variant(self.h, 1) == 1:
+        if self.lib.bcn_set_variant(self.h, 1) == 1 and os.environ.get("BEACON_JIT_FORCE") != "1":
             return
         from . import jit
         p = jit.plugin_for(self.nx, self.ny, self.tdtype == torch.float64, kind)
