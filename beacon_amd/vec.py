@@ -227,6 +227,18 @@ class VecEnv(object):
                 self._apply_mask(None)
         return self.obs, self.rwd, self.done, self.trunc, None
 
+    def capture(self, actions, noise=None, n_steps=None, keep_steps=True):
+        """Record step() calls into ONE HIP graph (torch.cuda.CUDAGraph) and return it as a StepGraph: replay()
+        relaunches them with a single host call.  step() only enqueues work on the current stream (no host
+        synchronisation, no host read), so it can be captured -- on its own, as here, or inside a caller's graph next to
+        the policy network.  For the 1D envs at the reference batch sizes the kernel of one step (38 us, burgers B=1024)
+        is shorter than the host work of launching it through Python; a graph of n steps runs at the kernel rate.
+        `actions` (and `noise`): STATIC device tensors the graph reads at every replay -- [B, ...] for one step, or
+        [n_steps, B, ...] for n_steps steps (step k uses actions[k]); overwrite them in place between replays.
+        keep_steps=False leaves out the per-step copies of obs / rwd / done / trunc (only the last step's stay, in the
+        env's own tensors): every extra graph node costs a few microseconds between two kernels."""
+        return StepGraph(self, actions, noise, n_steps, keep_steps)
+
     def reset_done(self):
         """Auto-reset: re-initialise the replicas whose last step() returned done (their rows of
         `obs` become the reset observation).  Entirely on the device, no host synchronisation."""
@@ -241,6 +253,42 @@ class VecEnv(object):
             self._step(actions, None)
         self.set_stp(0)
         return self.get_state()
+
+
+class StepGraph(object):
+    """n step() calls of one VecEnv on static inputs, as a HIP graph (VecEnv.capture).  After replay() the env's own
+    obs / rwd / done / trunc hold the last step's results; `obs_seq`, `rwd_seq`, `done_seq`, `trunc_seq` ([n, B, ...])
+    hold every step's."""
+
+    def __init__(self, env, actions, noise=None, n_steps=None, keep_steps=True):
+        self.env, self.actions, self.noise = env, actions, noise
+        self.n = 1 if n_steps is None else int(n_steps)
+        seq = n_steps is not None
+        n = self.n if keep_steps else 0
+        self.obs_seq = torch.empty((n,) + tuple(env.obs.shape), dtype=env.obs.dtype, device=env.device)
+        self.rwd_seq = torch.empty((n,) + tuple(env.rwd.shape), dtype=env.rwd.dtype, device=env.device)
+        self.done_seq = torch.empty((n,) + tuple(env.done.shape), dtype=env.done.dtype, device=env.device)
+        self.trunc_seq = torch.empty((n,) + tuple(env.trunc.shape), dtype=env.trunc.dtype, device=env.device)
+        self.graph = torch.cuda.CUDAGraph()
+        gen = getattr(env, "gen", None)
+        if gen is not None and noise is None:
+            self.graph.register_generator_state(gen)      # the env draws its own noise: a graph-safe generator
+        torch.cuda.synchronize(env.device)
+        with torch.cuda.graph(self.graph):
+            for k in range(self.n):
+                a = actions[k] if seq else actions
+                z = None if noise is None else (noise[k] if seq else noise)
+                env._step(a, z)
+                if not keep_steps:
+                    continue
+                self.obs_seq[k].copy_(env.obs)
+                self.rwd_seq[k].copy_(env.rwd)
+                self.done_seq[k].copy_(env.done)
+                self.trunc_seq[k].copy_(env.trunc)
+
+    def replay(self):
+        self.graph.replay()
+        return self.obs_seq, self.rwd_seq, self.done_seq, self.trunc_seq
 
 
 # ---------------------------------------------------------------------------------------------

@@ -215,6 +215,21 @@ def secondary_lines(dev, quick_steps=4):
         env.check_status()
         return float(np.mean([s.elapsed_time(e) for s, e in ev]))
 
+    def timed_graph(env, actions, noise=None, n=16, reps=5):
+        """The same step recorded n times into one HIP graph (VecEnv.capture): ms per step at replay -- what a trainer
+        that records its loop sees instead of the per-launch host work of Python."""
+        g = env.capture(actions.unsqueeze(0).expand(n, *actions.shape).contiguous(), noise, n_steps=n, keep_steps=False)
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        env.check_status()
+        return s.elapsed_time(e) / (reps * n)
+
     def line(name, env, ms, alg_bytes, extra=None):
         d = {"workload": name, "value": env.batch / (ms * 1e-3), "unit": "env steps/s", "ms_per_launch": ms,
              "kernel": env.kernel_name, "dtype": "f64" if env.tdtype == torch.float64 else "f32",
@@ -255,20 +270,23 @@ def secondary_lines(dev, quick_steps=4):
     env.reset()
     a1 = torch.as_tensor(rng.uniform(-1, 1, (1024,)), dtype=env.tdtype, device=dev)
     ms = timed(env, lambda: env.step(a1), 50, warm=5)
-    line("burgers-v0 N=512 B=1024 float32 (configs[1])", env, ms, 12.0 * 512 * env.ndt_act * 1024)
+    line("burgers-v0 N=512 B=1024 float32 (configs[1])", env, ms, 12.0 * 512 * env.ndt_act * 1024,
+         {"ms_per_step_in_hip_graph": timed_graph(env, a1, torch.stack([env.draw_noise() for _ in range(16)]))})
     env.close()
     # shkadov N=4096 10 jets B=1024 (configs[2]): 32 B per cell per timestep
     env = V.VecShkadov(1024, dev, "f32", None, L0=699.2, n_jets=10)
     env.reset()
     a10 = torch.as_tensor(rng.uniform(-1, 1, (1024, 10)), dtype=env.tdtype, device=dev)
     ms = timed(env, lambda: env.step(a10), 30, warm=5)
-    line("shkadov-v0 N=4096 10 jets B=1024 float32 (configs[2])", env, ms, 32.0 * env.nx * env.ndt_act * 1024)
+    line("shkadov-v0 N=4096 10 jets B=1024 float32 (configs[2])", env, ms, 32.0 * env.nx * env.ndt_act * 1024,
+         {"ms_per_step_in_hip_graph": timed_graph(env, a10, torch.stack([env.draw_noise() for _ in range(16)]))})
     env.close()
     # sloshing (reference default grid) B=1024: 32 B per cell per timestep
     env = V.VecSloshing(1024, dev, "f32", packaged_init("sloshing"))
     env.reset()
     ms = timed(env, lambda: env.step(a1), 50, warm=5)
-    line("sloshing-v0 N=200 B=1024 float32", env, ms, 32.0 * (env.nx + 2) * env.ndt_act * 1024)
+    line("sloshing-v0 N=200 B=1024 float32", env, ms, 32.0 * (env.nx + 2) * env.ndt_act * 1024,
+         {"ms_per_step_in_hip_graph": timed_graph(env, a1)})
     env.close()
     return out
 

@@ -1390,3 +1390,54 @@ def test_plain_c_consumer_of_the_c_abi(tmp_path):
         for s_ in range(3):
             ob, rw, _, _, _ = o.step([0.25 * (b - 1.5) * (s_ + 1)], 0.02 * (b + 1) - 0.01 * s_)
             assert maxdiff(got_obs[(s_, b)], ob) <= 1e-12 and abs(got_rwd[(s_, b)] - rw) <= 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# HIP graphs: step() only enqueues work, so a trainer can record it (VecEnv.capture)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["burgers", "sloshing", "shkadov", "rayleigh"])
+def test_step_captured_in_a_hip_graph_replays_bit_identically(name):
+    rng = np.random.default_rng(11)
+    n, B = 3, 4
+
+    def make():
+        if name == "burgers":
+            return V.VecBurgers(B, DEV, "f32", nx=512)
+        if name == "sloshing":
+            return V.VecSloshing(B, DEV, "f32")
+        if name == "shkadov":
+            return V.VecShkadov(B, DEV, "f32", E.packaged_init("shkadov"), n_jets=5)
+        env = V.VecRayleigh(B, DEV, "f32", E.packaged_init("rayleigh"))
+        env.set_ndt_act(20)
+        return env
+
+    eager, rec = make(), make()
+    ashape = {"burgers": (2 * n, B), "sloshing": (2 * n, B), "shkadov": (2 * n, B, 5), "rayleigh": (2 * n, B, 10)}[name]
+    acts = torch.as_tensor(rng.uniform(-1, 1, ashape), dtype=eager.tdtype, device=DEV)
+    noise = None
+    if name == "burgers":
+        noise = torch.as_tensor(rng.uniform(-0.1, 0.1, (2 * n, B)), dtype=eager.tdtype, device=DEV)
+    if name == "shkadov":
+        noise = torch.as_tensor(rng.uniform(-5e-4, 5e-4, (2 * n, B, eager.ndt_act)), dtype=eager.tdtype, device=DEV)
+    eager.reset()
+    want = []
+    for k in range(2 * n):
+        obs, rwd, done, trunc, _ = eager.step(acts[k], None if noise is None else noise[k])
+        want.append((obs.clone(), rwd.clone(), done.clone()))
+    eager.check_status()
+    rec.reset()
+    a_in = acts[:n].clone()
+    z_in = None if noise is None else noise[:n].clone()
+    g = rec.capture(a_in, z_in, n_steps=n)                    # recording launches nothing
+    for rep in range(2):                                      # second replay: the episode goes on with new inputs
+        a_in.copy_(acts[rep * n:(rep + 1) * n])
+        if z_in is not None:
+            z_in.copy_(noise[rep * n:(rep + 1) * n])
+        obs_seq, rwd_seq, done_seq, _ = g.replay()
+        torch.cuda.synchronize()
+        for k in range(n):
+            o, r, d = want[rep * n + k]
+            assert torch.equal(obs_seq[k], o) and torch.equal(rwd_seq[k], r) and torch.equal(done_seq[k], d), (name, rep, k)
+    rec.check_status()
+    assert torch.equal(rec.get_state(), eager.get_state())
+    eager.close(); rec.close()
