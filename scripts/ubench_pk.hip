@@ -15,6 +15,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define P_PKMUL "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
 // dependent chain of packed fma (latency)
 #define P_PKDEP "v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n v_pk_fma_f32 %0, %0, %4, %1\n"
+#define P_RCP   "v_rcp_f32 %0, %1\n v_rcp_f32 %1, %2\n v_rcp_f32 %2, %3\n v_rcp_f32 %3, %0\n v_rcp_f32 %0, %1\n v_rcp_f32 %1, %2\n v_rcp_f32 %2, %3\n v_rcp_f32 %3, %0\n"
+#define P_CND   "v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %2, vcc\n v_cmp_lt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %0, vcc\n v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %2, vcc\n v_cmp_lt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %0, vcc\n"
+#define P_MED   "v_med3_f32 %0, %0, %4, %1\n v_med3_f32 %1, %1, %4, %2\n v_med3_f32 %2, %2, %4, %3\n v_med3_f32 %3, %3, %4, %0\n v_med3_f32 %0, %0, %4, %1\n v_med3_f32 %1, %1, %4, %2\n v_med3_f32 %2, %2, %4, %3\n v_med3_f32 %3, %3, %4, %0\n"
+#define P_MOV   "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0\n"
 template <int MODE>
 __global__ __launch_bounds__(1024) void kb(unsigned long long* out, float* sink) {
   v2f a = {1.f, 2.f}, b = {0.5f, 0.25f}, c = {3.f, 1.f}, d = {0.1f, 0.2f};
@@ -28,6 +32,12 @@ __global__ __launch_bounds__(1024) void kb(unsigned long long* out, float* sink)
     if (MODE == 2) asm volatile(REP16(P_PKSWP) OPS);
     if (MODE == 3) asm volatile(REP16(P_PKMUL) OPS);
     if (MODE == 4) asm volatile(REP16(P_PKDEP) OPS);
+    if (MODE >= 6) { float a0 = a.x, a1 = b.x, a2 = c.x, a3 = d.x, f = cf.x;
+      if (MODE == 6) asm volatile(REP16(P_RCP) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
+      if (MODE == 7) asm volatile(REP16(P_CND) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f) : "vcc");
+      if (MODE == 8) asm volatile(REP16(P_MED) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
+      if (MODE == 9) asm volatile(REP16(P_MOV) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
+      a.x = a0; b.x = a1; c.x = a2; d.x = a3; }
     if (MODE == 5) { float a0 = a.x, a1 = b.x, a2 = c.x, a3 = d.x, f = cf.x;
       asm volatile(REP16(P_FMA) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f)); a.x = a0; b.x = a1; c.x = a2; d.x = a3; }
   }
@@ -58,5 +68,9 @@ int main() {
   run<2>("v_pk_add_f32 op_sel swap", 8);
   run<3>("v_pk_mul_f32", 8);
   run<4>("v_pk_fma_f32 (dependent)", 8);
+  run<6>("v_rcp_f32", 8);
+  run<7>("v_cmp_lt_f32 + v_cndmask_b32", 8);
+  run<8>("v_med3_f32", 8);
+  run<9>("v_mov_b32", 8);
   return 0;
 }
