@@ -528,12 +528,16 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       yw = (w > 0) ? yw : Y[0];                                                              \
       ye = (w < NW - 1) ? ye : Y[R - 1];                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                     \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) X[k] = cell(Y[k], Y[k + 1], Y[k - 1], nb[k]); \
-      const real x0 = cell(Y[0], Y[1], yw, nb[0]), xl = cell(Y[R - 1], ye, Y[R - 2], nb[R - 1]); \
-      X[0] = x0;                                                                             \
-      X[R - 1] = xl;                                                                         \
+      /* the second sweep needs no halo: its four exchanged columns go FIRST, so that their LDS stores complete behind \
+         the interior cells instead of in front of the barrier */                             \
+      X[0] = cell(Y[0], Y[1], yw, nb[0]);                                                    \
+      X[1] = cell(Y[1], Y[2], Y[0], nb[1]);                                                  \
+      X[R - 2] = cell(Y[R - 2], Y[R - 1], Y[R - 3], nb[R - 2]);                              \
+      X[R - 1] = cell(Y[R - 1], ye, Y[R - 2], nb[R - 1]);                                    \
       hW = yw; hE = ye;                                                                      \
       BCN_PUBLISH(X)                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      _Pragma("unroll") for (int k = 2; k < R - 2; k++) X[k] = cell(Y[k], Y[k + 1], Y[k - 1], nb[k]); \
       __syncthreads();                                                                       \
       itp += 2;                                                                              \
       BCN_HALO_READS                                                                         \
