@@ -107,6 +107,7 @@ __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real*
 // A, u, v and for the result); blocks of four steps with two register sets, a block first requesting the next block's
 // operands.  The control flow stays uniform (EXEC-masked steps made hipcc wait for every LDS operation in flight at each
 // step): lanes in front of / behind the domain read a clamped address, keep their west values and write to `dummy`.
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int NX, int NY>
 __device__ __attribute__((noinline)) void transport_chain2_f32(float* Tl, const float* Ul, const float* Vl, float* dummy,
                                                                float c0x, float c1x, float c0y, float c1y) {
@@ -134,12 +135,16 @@ __device__ __attribute__((noinline)) void transport_chain2_f32(float* Tl, const 
     BCN_LOAD2(NA, NU, NV, (T0) + PD, NMASK)                                                   \
     _Pragma("unroll") for (int q = 0; q < PD; q++) {                                          \
       const int t = (T0) + q;                                                                 \
-      const float aw0 = c0x + c1x * RU[2 * q], as0 = c0y + c1y * RV[2 * q];                   \
-      const float aw1 = c0x + c1x * RU[2 * q + 1], as1 = c0y + c1y * RV[2 * q + 1];           \
-      float t0 = RA[2 * q] + aw0 * tp0;                                                       \
+      /* both rows per packed fma: a lone wave issues a v_pk_fma_f32 in the time of a v_fma_f32 */ \
+      const v2f ru = {RU[2 * q], RU[2 * q + 1]}, rv = {RV[2 * q], RV[2 * q + 1]}, ra = {RA[2 * q], RA[2 * q + 1]}; \
+      const v2f tpp = {tp0, tp1};                                                             \
+      const v2f awp = c0x + c1x * ru, asp = c0y + c1y * rv;                                   \
+      const v2f tw = ra + awp * tpp;                                                          \
+      const float as0 = asp.x, as1 = asp.y;                                                   \
+      float t0 = tw.x;                                                                        \
       asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"        \
           : "+v"(t0) : "v"(tp1), "v"(as0));                                                   \
-      float t1 = RA[2 * q + 1] + aw1 * tp1;                                                   \
+      float t1 = tw.y;                                                                        \
       t1 += as1 * t0;                                                                         \
       float* Tq = Tl + (cb + t * SY);                                                         \
       if (MASK != 0) {                                                                        \

@@ -101,6 +101,7 @@ struct FastGeom {
 // then computes its four steps from registers and stores them pairwise.  A lone wave issues one instruction per ~4.6
 // cycles whatever its kind: 14 -> 10 instructions per steady step; the ragged first and last thirds of the sweep carry three
 // mask instructions more.
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int NX, int NY, int R>
 __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const float* Ul, float* dummy, float c0x, float c1x,
                                                               float c0y, float c1y) {
@@ -132,9 +133,16 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
     float* const Tq = Tb + (T0) * SY;                                                         \
     float tq[PD];                                                                             \
     bool okq[PD];                                                                             \
+    /* the coefficients of two diagonals per packed fma: a lone wave issues a v_pk_fma_f32 in the time of a v_fma_f32 */ \
+    v2f awp[PD / 2], asp[PD / 2];                                                             \
+    _Pragma("unroll") for (int q = 0; q < PD / 2; q++) {                                      \
+      const v2f ru = {RU[2 * q], RU[2 * q + 1]}, rv = {RV[2 * q], RV[2 * q + 1]};             \
+      awp[q] = c0x + c1x * ru;                                                                \
+      asp[q] = c0y + c1y * rv;                                                                \
+    }                                                                                         \
     _Pragma("unroll") for (int q = 0; q < PD; q++) {                                          \
       const int t = (T0) + q;                                                                 \
-      const float aw = c0x + c1x * RU[q], as = c0y + c1y * RV[q];                             \
+      const float aw = awp[q / 2][q & 1], as = asp[q / 2][q & 1];                             \
       float t1 = RA[q] + aw * tp;                                                             \
       asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
                    : "+v"(t1) : "v"(tp), "v"(as));                                            \
