@@ -52,6 +52,7 @@ struct NS2DArgs {
   size_t sched_bytes;       // bytes of sched_ctl + cyc: zeroed by one memset in front of every step launch
   int sched_q;              // timesteps per chunk
   int conv_plan = 1;        // which Jacobi sweeps evaluate the residual: 0 all, 1 proven skips only, 2 + extrapolated (ns2d_fast.hip)
+  int spec_start = 0;       // first evaluation of a solve at spec_start/8 of the previous timestep's sweep count (0: at sweep 1): ns2d_fast_impl.h
   int verify_conv = 0;      // 1: evaluate the Jacobi residual after every sweep and flag BCN_ST_PLAN if the evaluation plan
                             //    of the register-resident kernels would have skipped a sweep that passes the test (BCN_VERIFY_CONV=1)
   int sched_mode = -1;      // per-handle overrides of the BCN_SCHED* defaults (bcn_set_sched): -1 / 0 = default

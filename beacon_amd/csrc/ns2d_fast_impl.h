@@ -327,6 +327,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   if (!first_chunk) status = A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
   const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
   unsigned long long cyc_j = 0;
+  // sweeps of the previous timestep's solve, kept in LDS (red[20]; 0 = unknown: the first timestep of an action step
+  // starts without a guess) -- see "Speculative jump" below
+  real* const prev_sweeps = red + 20;
+#if !defined(BCN_STAMP) && !defined(BCN_DBG_NCHK)
+  if (tid == 0) prev_sweeps[0] = (it_begin > 0 && A.sweeps) ? (real)A.sweeps[(size_t)b * A.ndt_act + it_begin - 1] : real(0);
+#else
+  if (tid == 0) prev_sweeps[0] = 0;
+#endif
   for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
@@ -483,7 +491,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     bool finalB = false;
     int k_prev = -1;                // index of the planned evaluation before the last one, log2 of its two norms
     float l2u_prev = 0, l2w_prev = 0;
-    int skip_left = 0;              // verify_conv: sweeps the plan would still skip
+    int skip_left = 0;              // verify_conv: sweeps the plan would still skip; -2 / -1: speculative jump pending / failed
+    // Speculative jump.  The norm never increases from one sweep to the next (|lambda_i| <= 1; the reference norm adds
+    // the ghost copies), so behind the evaluations of sweeps 1 and 2 the next one may sit at sweep m: if it does not pass,
+    // no sweep in between did.  m = spec_start/8 of the previous timestep's count (consecutive timesteps of the bench
+    // workload differ by < 30 % in 611 000 solves).  If the evaluation at m DOES pass the test (or, under the proven plan,
+    // its unweighted norm is not above the threshold), the whole timestep is repeated without the jump -- the result never
+    // depends on the guess.  The bookkeeping lives in `skip_left` (unused without verify_conv) and in LDS: every scalar
+    // register more in this loop costs hipcc dozens of SGPR spills (v_readlane) around the sweeps.
 #ifdef BCN_DBG_NCHK
     int nchk = 0;
 #define BCN_NCHK_INC nchk++;
@@ -575,10 +590,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       BCN_HALO_READS                                                                         \
       const real esum = row16_sum<real>(epart);                                              \
       const real err = read_lane(esum, 15);                                                  \
-      if (!(err > A.tol)) {                                                                  \
+      /* behind the speculative jump the proven plan also needs the unweighted norm above its threshold */ \
+      const bool amb = skip_left == -2 && A.conv_plan == 1 && !(read_lane(esum, 31) > A.tol * real(1.02)); \
+      if (!(err > A.tol) || amb) {                                                           \
         if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
+        skip_left = skip_left == -2 ? -1 : 0;                                                \
         finalB = DST_IS_B; break;                                                            \
       }                                                                                      \
+      skip_left = skip_left < 0 ? 0 : skip_left;                                             \
       if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; }               \
       n = 0;                                                                                 \
       if (skip_left > 0) {                                                                   \
@@ -615,6 +634,11 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         BCN_FAST(phB, phA)
         n = (n - 1) & ~1;
       }
+      if (itp == 2 && A.spec_start > 0 && A.conv_plan > 0 && !A.verify_conv) {   // first pass: the speculative jump
+        const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
+        const int ns = ((prev * A.spec_start) >> 3) - 2;
+        if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }
+      }
       if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
       if constexpr (XC == 4) {
         for (; n > 0; n -= 2) BCN_FAST2X(phA, phB)
@@ -632,6 +656,12 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #undef BCN_FAST
 #undef BCN_SWEEP_END
 #undef BCN_CELLS
+    if (skip_left == -1) {   // the speculative jump went too far (cold): this timestep again -- BC, predictor and rhs
+      if (tid == 0) prev_sweeps[0] = 0;   // recompute the same values from the unchanged fields -- and its solve without a guess
+      it--;
+      continue;
+    }
+    if (tid == 0) prev_sweeps[0] = (real)itp;
     if (finalB) {
 #pragma unroll
       for (int k = 0; k < R; k++) phA[k] = phB[k];

@@ -552,6 +552,32 @@ def test_convergence_plan_never_skips_a_passing_sweep():
         assert torch.equal(planned[i][1], literal[j][1]) and torch.equal(planned[i][2], literal[j][2])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_speculative_first_evaluation_never_changes_a_result(dtype):
+    """ns2d_fast_impl.h starts a Jacobi solve with spec_start/8 of the previous timestep's sweep count as double sweeps
+    before the first evaluation of the residual (the norm never increases, so a first evaluation that does not pass
+    proves that no earlier sweep did) and repeats the solve in the ordinary way when that first evaluation passes.
+    spec_start = 16 (twice the previous count) overshoots in every timestep and so runs the repeat path; all settings must
+    give the sweep counts and fields of spec_start = 0 bit for bit (full action step of the bench workload, 200 timesteps,
+    ticket scheduler and plain launch)."""
+    ref = {}
+    for spec, sched in ((0, 0), (4, 0), (7, 0), (16, 0), (0, 2), (6, 2), (16, 2)):
+        env, init, acts = _bench_workload(300, 1, dtype)
+        env.set_option("spec_start", spec)
+        env.set_sched(sched)
+        env.step(acts[0])
+        env.check_status()
+        got = (env.sweeps.clone(), env.get_state().clone(), env.obs.clone())
+        env.close()
+        if spec == 0:                    # (the p ghosts of the two launch modes differ in the last bit: chunked increments)
+            ref[sched] = got
+            assert int(got[0].min()) >= 1 and int(got[0].max()) > 100
+        else:
+            for a, b in zip(ref[sched], got):
+                assert torch.equal(a, b), (spec, sched)
+    assert torch.equal(ref[0][0], ref[2][0]) and torch.equal(ref[0][2], ref[2][2])
+
+
 @pytest.mark.parametrize("L,H,dtype,tol", [(1.5, 1.0, "f32", 5e-5), (1.5, 1.0, "f64", F64_TOL), (1.06, 1.0, "f32", 5e-5),
                                             (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
                                             (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL)])
