@@ -90,7 +90,9 @@ struct NS2DEnv : bcn_env_s {
     variant = fast_ok ? 1 : 0;
     a.conv_plan = sizeof(real) == 4 ? 2 : 1;   // ns2d_fast.hip: float64 keeps the proven plan (exact stop sweep)
     if (const char* e = getenv("BCN_CONV_PLAN")) a.conv_plan = atoi(e);
-    a.spec_start = a.kind == 0 ? 6 : 0;   // rayleigh: consecutive timesteps never differed by more than 30 % (611 000 solves); mixing's do
+    // rayleigh float32: consecutive timesteps never differed by more than 30 % (611 000 solves); mixing's do; the float64
+    // kernels are built without the jump (ns2d_fast_impl.h)
+    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 6 : 0;
     if (const char* e = getenv("BCN_SPEC_START")) a.spec_start = atoi(e);
     return BCN_OK;
   }

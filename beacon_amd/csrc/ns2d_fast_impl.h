@@ -330,6 +330,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   // sweeps of the previous timestep's solve, kept in LDS (red[20]; 0 = unknown: the first timestep of an action step
   // starts without a guess) -- see "Speculative jump" below
   real* const prev_sweeps = red + 20;
+  // float32 only: the float64 default is the proven plan, which evaluates every ~4th sweep anyway and needs the unweighted
+  // norm above its threshold behind a jump (measured: no gain, and the code costs the float64 instantiation 6 %)
+  constexpr bool SPEC = std::is_same<real, float>::value;
 #if !defined(BCN_STAMP) && !defined(BCN_DBG_NCHK)
   if (tid == 0) prev_sweeps[0] = (it_begin > 0 && A.sweeps) ? (real)A.sweeps[(size_t)b * A.ndt_act + it_begin - 1] : real(0);
 #else
@@ -591,13 +594,13 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real esum = row16_sum<real>(epart);                                              \
       const real err = read_lane(esum, 15);                                                  \
       /* behind the speculative jump the proven plan also needs the unweighted norm above its threshold */ \
-      const bool amb = skip_left == -2 && A.conv_plan == 1 && !(read_lane(esum, 31) > A.tol * real(1.02)); \
+      const bool amb = SPEC && skip_left == -2 && A.conv_plan == 1 && !(read_lane(esum, 31) > A.tol * real(1.02)); \
       if (!(err > A.tol) || amb) {                                                           \
         if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
-        skip_left = skip_left == -2 ? -1 : 0;                                                \
+        if (SPEC) skip_left = skip_left == -2 ? -1 : 0;                                      \
         finalB = DST_IS_B; break;                                                            \
       }                                                                                      \
-      skip_left = skip_left < 0 ? 0 : skip_left;                                             \
+      if (SPEC) skip_left = skip_left < 0 ? 0 : skip_left;                                   \
       if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; }               \
       n = 0;                                                                                 \
       if (skip_left > 0) {                                                                   \
@@ -634,7 +637,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         BCN_FAST(phB, phA)
         n = (n - 1) & ~1;
       }
-      if (itp == 2 && A.spec_start > 0 && A.conv_plan > 0 && !A.verify_conv) {   // first pass: the speculative jump
+      if (SPEC && itp == 2 && A.spec_start > 0 && A.conv_plan > 0 && !A.verify_conv) {   // first pass: the speculative jump
         const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
         const int ns = ((prev * A.spec_start) >> 3) - 2;
         if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }
@@ -656,12 +659,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #undef BCN_FAST
 #undef BCN_SWEEP_END
 #undef BCN_CELLS
-    if (skip_left == -1) {   // the speculative jump went too far (cold): this timestep again -- BC, predictor and rhs
-      if (tid == 0) prev_sweeps[0] = 0;   // recompute the same values from the unchanged fields -- and its solve without a guess
-      it--;
-      continue;
+    if constexpr (SPEC) {
+      if (skip_left == -1) {   // the speculative jump went too far (cold): this timestep again -- BC, predictor and rhs
+        if (tid == 0) prev_sweeps[0] = 0;   // recompute the same values from the unchanged fields -- and its solve without a guess
+        it--;
+        continue;
+      }
+      if (tid == 0) prev_sweeps[0] = (real)itp;
     }
-    if (tid == 0) prev_sweeps[0] = (real)itp;
     if (finalB) {
 #pragma unroll
       for (int k = 0; k < R; k++) phA[k] = phB[k];

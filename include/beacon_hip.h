@@ -192,7 +192,7 @@ BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_ele
  *   "spec_start"  0..16: behind the evaluations of sweeps 1 and 2, place the next evaluation at spec_start/8 of the
  *                 previous timestep's sweep count (the norm never increases: if that evaluation does not pass, no
  *                 earlier sweep did; if it does, the timestep is repeated without the guess, so results never depend
- *                 on it).  Default 6 for rayleigh, 0 (off) for mixing
+ *                 on it).  BCN_F32 rayleigh only (default 6); ignored by BCN_F64 handles and off for mixing
  * Returns BCN_ERR_ARG for unknown names. */
 BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference

@@ -559,7 +559,7 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
     proves that no earlier sweep did) and repeats the solve in the ordinary way when that first evaluation passes.
     spec_start = 16 (twice the previous count) overshoots in every timestep and so runs the repeat path; all settings must
     give the sweep counts and fields of spec_start = 0 bit for bit (full action step of the bench workload, 200 timesteps,
-    ticket scheduler and plain launch)."""
+    ticket scheduler and plain launch).  The float64 kernels are built without the jump: there the option must be inert."""
     ref = {}
     for spec, sched in ((0, 0), (4, 0), (7, 0), (16, 0), (0, 2), (6, 2), (16, 2)):
         env, init, acts = _bench_workload(300, 1, dtype)
