@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--zero-actions", action="store_true",
                     help="diagnostic: uncontrolled steady flow (1 Jacobi sweep per timestep) -> non-Poisson cost")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --stub)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; nccl needs one device per rank)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU stand-in env (no GPU, no kernels): exercises launcher, sharding and gather only; "
                          "its line is marked data=stub and is not a measurement")
@@ -313,11 +315,13 @@ def main():
     if args.stub:
         dev = "cpu"
     else:
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.stub:
+        if args.stub or args.backend != "nccl":
             dist.init_process_group(args.backend)
         else:
             dist.init_process_group(args.backend, device_id=torch.device(dev))
@@ -440,7 +444,7 @@ def main():
             "config": {"workload": "rayleigh-v0 (BASELINE configs[3]): L=2.56 H=1.28 -> 128x64 MAC grid, "
                                    "%d replicas per GPU, 200 timesteps per step, Jacobi to tol=1e-8" % B,
                        "global_batch": Bg, "grid": [env.nx, env.ny], "ndt_act": env.ndt_act,
-                       "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world,
+                       "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world + (" (rehearsal: all ranks on cuda:0)" if args.share_gpu else ""),
                        "kernel": kname},
             "roofline": roof,
         }

@@ -1467,3 +1467,67 @@ def test_step_captured_in_a_hip_graph_replays_bit_identically(name):
     rec.check_status()
     assert torch.equal(rec.get_state(), eager.get_state())
     eager.close(); rec.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8e on real kernels: two ranks (two processes) sharing the one GPU of the box, device tensors over gloo
+# (the nccl backend needs one device per rank: it runs only in the driver's multi-GPU bench)
+# ---------------------------------------------------------------------------------------------
+_GPU_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from beacon_amd import vec as V
+from beacon_amd.dist import ShardedVecEnv
+from beacon_amd.envs import packaged_init
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+dev, Bl = "cuda:0", 3
+rng = np.random.default_rng(5)
+for name in ("rayleigh", "burgers"):
+    def make(B):
+        if name == "rayleigh":
+            e = V.VecRayleigh(B, dev, "f32", packaged_init("rayleigh")); e.set_ndt_act(20); return e
+        return V.VecBurgers(B, dev, "f32", nx=512)
+    env = make(Bl)
+    senv = ShardedVecEnv(env)
+    o0, _ = senv.reset()
+    shape = (3, world * Bl, 10) if name == "rayleigh" else (3, world * Bl)
+    acts = torch.as_tensor(rng.uniform(-1, 1, shape), dtype=torch.float32)
+    noise = None if name == "rayleigh" else torch.zeros((Bl,), dtype=torch.float32, device=dev)
+    outs = [senv.step(acts[k] if rank == 0 else None, noise) for k in range(3)]
+    if rank == 0:
+        ref = make(world * Bl)
+        ref.reset()
+        assert torch.equal(o0, ref.obs), name
+        nz = None if noise is None else torch.zeros((world * Bl,), dtype=torch.float32, device=dev)
+        for k in range(3):
+            obs, rwd, done, trunc, _ = ref.step(acts[k], nz)
+            o, r, d, t, _ = outs[k]
+            assert o.shape == obs.shape and torch.equal(o, obs) and torch.equal(r, rwd) and torch.equal(d, done), (name, k)
+        assert int(senv.gather_status().max()) == 0
+        ref.close()
+    else:
+        assert all(x[0] is None for x in outs)
+    senv.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
+    """ShardedVecEnv end to end with the real kernels: rank 0 scatters the global actions, every rank steps its shard on
+    the GPU, one packed gather brings obs / rwd / status / done / trunc back -- bit-identical to one process stepping the
+    global batch (replicas are independent)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(_GPU_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
