@@ -43,8 +43,9 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
   return s;
 }
 
-template <typename T>
-__device__ __forceinline__ T bcn_abs(T x) { return x < T(0) ? -x : x; }
+// |x| as the instruction's source modifier (free); the compare + select form costs two instructions of two issue slots each
+__device__ __forceinline__ float bcn_abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double bcn_abs(double x) { return __builtin_fabs(x); }
 
 // ---- handle ------------------------------------------------------------------------------
 struct bcn_env_s {
