@@ -329,6 +329,87 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     __syncthreads();
     BCN_PH(0)
 
+    // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* in place of u, v --------------------
+    if constexpr (GF != 0) {
+      // Fields in the global scratch (float64): column by column, west to east, over a sliding window of three columns x
+      // four rows (j0-1 .. j0+2: contiguous, one wide load per field and column) -- a fifth of the loads of the row-wise
+      // form below, whose 12 loads per cell are what this phase waits for when the fields are not in LDS.  u*, v* of column
+      // k-1 are written once column k is computed: by then every reader of the old column k-1 -- columns k-2, k-1, k of
+      // this wave, all rows in the same instructions -- has its values in registers.  Only the strip's first and last
+      // column are read by OTHER waves: they wait for the barrier.
+      const real pWh0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0);
+      const real pWh1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
+      xb ^= 1;
+      // ring of columns i0-1 .. (loaded PF columns ahead of their use: the loads are global); column i0-1+q sits in slot q % NC
+      constexpr int PF = 3, NC = 3 + PF;
+      real uw[NC][4], vw[NC][4];      // [slot][row j0-1, j0, j0+1, j0+2]
+      auto load_col = [&](real (&uc)[4], real (&vc)[4], const int i) {
+        const int c = i * SY + j0 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { uc[r] = Ul[c + r]; vc[r] = Vl[c + r]; }
+      };
+#pragma unroll
+      for (int q = 0; q < 2 + PF; q++)
+        if (q <= RW + 1) load_col(uw[q % NC], vw[q % NC], i0 - 1 + q);
+      real usF[2], vsF[2], usP[2] = {0, 0}, vsP[2] = {0, 0};   // first column (deferred) / previous column (pending)
+#pragma unroll
+      for (int k = 0; k < RW; k++) {
+        const int i = i0 + k;
+        if (k + 2 + PF <= RW + 1) load_col(uw[(k + 2 + PF) % NC], vw[(k + 2 + PF) % NC], i0 - 1 + k + 2 + PF);
+        const int sW = k % NC, sC = (k + 1) % NC, sE = (k + 2) % NC;   // slots of columns k-1, k, k+1 (compile-time: k is unrolled)
+        real usk[2], vsk[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          const int j = j0 + a, r = a + 1;
+          const real uc = uw[sC][r], uE_ = uw[sE][r], uW_ = uw[sW][r], uN_ = uw[sC][r + 1], uS_ = uw[sC][r - 1];
+          const real vc = vw[sC][r], vE_ = vw[sE][r], vW_ = vw[sW][r], vN_ = vw[sC][r + 1], vS_ = vw[sC][r - 1];
+          const real pc = p[a][k];
+          const real pW = (k > 0) ? p[a][k > 0 ? k - 1 : 0] : (a == 0 ? pWh0 : pWh1);
+          const real pS = (a == 0) ? from_below(p[1][k], p[1][k]) : p[0][k];
+          {
+            real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+            real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vw[sW][r + 1]), vS2 = real(0.5) * (vc + vW_);
+            real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
+            real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
+            real pres = (pc - pW) * rdx;
+            usk[a] = (i >= 2) ? uc + dt * (diff - conv - pres) : real(0);
+          }
+          {
+            real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+            real uE = real(0.5) * (uE_ + uw[sE][r - 1]), uW = real(0.5) * (uc + uS_);
+            real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
+            real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
+            real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
+            real pres = (pc - pS) * rdy;
+            const real buoy = (KIND == 0) ? Tl[i * SY + j] : real(0);
+            vsk[a] = (j >= 2) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+          }
+        }
+        // the pending column k-1 (not the strip's first one) goes to memory now: the wave-wide loads of that column have
+        // returned (their data went into column k-2 .. k), and the loads in flight are of columns >= k+2
+        if (k >= 2) {
+          if (active) {
+            const int c = (i - 1) * SY + j0;
+            Ul[c] = usP[0]; Vl[c] = vsP[0];
+            if (act1) { Ul[c + 1] = usP[1]; Vl[c + 1] = vsP[1]; }
+          }
+        }
+        if (k == 0) { usF[0] = usk[0]; usF[1] = usk[1]; vsF[0] = vsk[0]; vsF[1] = vsk[1]; }
+        usP[0] = usk[0]; usP[1] = usk[1]; vsP[0] = vsk[0]; vsP[1] = vsk[1];
+      }
+      __syncthreads();   // every read of the old first / last column by the neighbouring strips is done
+      if (active) {
+        const int cF = i0 * SY + j0, cL = (i0 + RW - 1) * SY + j0;
+        Ul[cF] = usF[0]; Vl[cF] = vsF[0];
+        Ul[cL] = usP[0]; Vl[cL] = vsP[0];
+        if (act1) {
+          Ul[cF + 1] = usF[1]; Vl[cF + 1] = vsF[1];
+          Ul[cL + 1] = usP[1]; Vl[cL + 1] = vsP[1];
+        }
+      }
+      __syncthreads();
+    } else {
     // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* (registers, then LDS) ---
     real us[2][RW], vs[2][RW];
     {
@@ -389,6 +470,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         }
     }
     __syncthreads();
+    }
 
     // ---- Poisson rhs from u*, v* in LDS (u*[1,.] = u*[nx+1,.] = v*[.,1] = v*[.,ny+1] = 0 are the
     //      wall values the BC pass left there) ------------------------------------------------

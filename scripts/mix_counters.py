@@ -2,7 +2,7 @@
 import os, sys, numpy as np, torch, time
 sys.path.insert(0, os.getcwd())
 from beacon_amd import vec as V
-env = V.VecMixing(512, "cuda:0", "f32"); env.reset()
+env = V.VecMixing(512, "cuda:0", sys.argv[1] if len(sys.argv) > 1 else "f32"); env.reset()
 rng = np.random.default_rng(7)
 for k in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
