@@ -204,7 +204,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   constexpr bool ODD = (NY & 1) != 0;
   const bool act1 = active && !(ODD && lane == LH - 1);   // the upper row of the pair exists (odd ny: not in the last lane)
   const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
-  const int j0 = 2 * la + 1;                 // rows j0 (a = 0) and j0 + 1 (a = 1)
+  int j0 = 2 * la + 1;                       // rows j0 (a = 0) and j0 + 1 (a = 1); GF: laundered once per timestep (below)
   const int i0 = w * R + 1;
   const size_t off = (size_t)b * A.ncell;
   real* __restrict__ gu = A.u + off;
@@ -294,6 +294,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
   unsigned long long cyc_j = 0;
   for (int it = it_begin; it < it_end && status == 0; it++) {
+    // fields in the global scratch: keep hipcc from hoisting the (64-bit) addresses of a whole timestep out of the loop
+    if (GF) asm volatile("" : "+v"(j0));
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202 / mixing.py:153-171) ------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
       Ul[1 * SY + jj] = 0;
@@ -327,6 +329,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     ex(xb, w, 1, 0)[lane] = p[0][RW - 1];
     ex(xb, w, 1, 1)[lane] = p[1][RW - 1];
     __syncthreads();
+    if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(0)
 
     // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* in place of u, v --------------------
@@ -638,6 +641,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
 
     cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
+    if (GF) asm volatile("" : "+v"(j0));   // (the addresses of the phases below are not kept across the solve)
     BCN_PH(2)
     // ---- p += phi, corrector: u = u* - dt dphi/dx, v = v* - dt dphi/dy (in place in LDS) -------
 #pragma unroll
@@ -659,6 +663,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     }
     __syncthreads();
 
+    if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(3)
     // ---- transport: explicit part of every cell, then the ordered part by one wave ------------
     {
@@ -684,6 +689,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       }
     }
     __syncthreads();
+    if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(4)
     if (w == 0) {
       if constexpr (std::is_same<real, float>::value && GF == 0)
