@@ -255,7 +255,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   real* Tl = GF == 2 ? gscr : Vl + SZ;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int j = lane + 1;
+  int j = lane + 1;   // GF: laundered at the phase boundaries (hipcc would hoist and spill a timestep's 64-bit addresses)
   const bool active = lane < NY;
   const int i0 = w * R0 + 1;
   const size_t off = (size_t)b * A.ncell;
@@ -339,6 +339,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   if (tid == 0) prev_sweeps[0] = 0;
 #endif
   for (int it = it_begin; it < it_end && status == 0; it++) {
+    if (GF) asm volatile("" : "+v"(j));
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
       Ul[1 * SY + jj] = 0;
@@ -366,6 +367,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     }
     ex(xb, w, 1)[lane] = p[R - 1];
     __syncthreads();
+    if (GF) asm volatile("" : "+v"(j));
     BCN_PH(0)
 
     // ---- predictor (rayleigh.py:370-407) -> u*, v* in registers -----------------------------
@@ -685,6 +687,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #endif
 
     cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
+    if (GF) asm volatile("" : "+v"(j));
     BCN_PH(2)
     // ---- p += phi (rayleigh.py:219), corrector (rayleigh.py:460-464) -> LDS u, v --------------
 #pragma unroll
@@ -701,6 +704,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     }
     __syncthreads();
 
+    if (GF) asm volatile("" : "+v"(j));
     BCN_PH(3)
     // ---- transport, explicit part of every cell (rayleigh.py:468-487) ------------------------
     {
@@ -723,6 +727,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     }
     __syncthreads();
 
+    if (GF) asm volatile("" : "+v"(j));
     BCN_PH(4)
     // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
     if (w == 0) {
