@@ -666,7 +666,38 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(3)
     // ---- transport: explicit part of every cell, then the ordered part by one wave ------------
-    {
+    if constexpr (GF != 0) {
+      // Fields in the global scratch: column by column, west to east.  A cell reads the OLD value of its east and north
+      // neighbours, so a column can be written as soon as it is computed: its readers are the column to its west (this lane,
+      // earlier in program order) and the row below (this wave, the same load instruction, whose data the store depends
+      // on).  Only the strip's first column is read by ANOTHER wave: it waits for the barrier (2 live values instead of
+      // 2 * RW float64 pairs).
+      real A0[2];
+#pragma unroll
+      for (int k = 0; k < RW; k++) {
+        real Ak[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          const int c = (i0 + k) * SY + j0 + a;
+          const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
+          const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
+          const real expl = A.ksc * ((TE - 2 * T0) * rdx2 + (TN - 2 * T0) * rdy2) -
+                            (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
+                            (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
+          Ak[a] = T0 + dt * expl;
+        }
+        if (k == 0) { A0[0] = Ak[0]; A0[1] = Ak[1]; }
+        else if (active) {
+          Tl[(i0 + k) * SY + j0] = Ak[0];
+          if (act1) Tl[(i0 + k) * SY + j0 + 1] = Ak[1];
+        }
+      }
+      __syncthreads();
+      if (active) {
+        Tl[i0 * SY + j0] = A0[0];
+        if (act1) Tl[i0 * SY + j0 + 1] = A0[1];
+      }
+    } else {
       real Ac[2][RW];
 #pragma unroll
       for (int a = 0; a < 2; a++)
