@@ -23,6 +23,9 @@
 
 #include <type_traits>
 
+#ifndef BCN_PDG2
+#define BCN_PDG2 8    // prefetch depth of the transport wave when the fields are in global memory
+#endif
 #include "bcn_dpp.h"
 #include "ns2d.h"
 #include "ns2d_device.h"
@@ -56,10 +59,10 @@ struct Fast2Geom {
 // west values in registers, the south value of the lower row from the lane below (its upper row of
 // the previous step) and the explicit part A, u, v prefetched PD steps ahead from LDS.  Lanes outside
 // the domain compute on clamped addresses and write to `dummy`.
-template <typename real, int NX, int NY>
+template <typename real, int NX, int NY, int PD>
 __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real* Ul, const real* Vl, real* dummy,
                                                            real c0x, real c1x, real c0y, real c1y) {
-  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2, PD = 4;
+  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2;   // PD: steps of prefetch (4 from LDS, more from global memory)
   constexpr bool ODD = (NY & 1) != 0;
   constexpr int NSTEP = NX + LH - 1;
   const int lane = threadIdx.x & 63;
@@ -726,7 +729,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       if constexpr (std::is_same<real, float>::value && GF == 0)
         transport_chain2_f32<NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2, real(0.5) * dt * rdy);
       else
-        transport_chain2<real, NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+        transport_chain2<real, NX, NY, (GF ? BCN_PDG2 : 4)>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
                                        dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     }
     __syncthreads();
