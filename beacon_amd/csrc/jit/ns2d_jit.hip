@@ -5,6 +5,9 @@
 // (ROWS: rows per lane: 1 = ns2d_fast_impl.h, ny <= 64; 2 = ns2d_fast2_impl.h, 64 < ny <= 128.)
 // The reference takes any L, H (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: 100 L, 100 H); the library
 // hands the argument block of a step to bcn_jit_launch through bcn_set_fast_plugin (include/beacon_hip.h).
+#if BCN_JIT_ROWS == 1 && BCN_JIT_KIND != 0
+#error "ns2d_fast_impl.h (one row per lane, ny <= 64) implements the rayleigh boundary conditions only: mixing needs BCN_JIT_ROWS=2"
+#endif
 #if BCN_JIT_ROWS == 1
 #include "../ns2d_fast_impl.h"
 #else

@@ -897,6 +897,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
 
 template <typename real, int NX, int NY, int R, int KIND, int GF = 0>
 int launch_fast(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  static_assert(KIND == 0, "fast_body applies the rayleigh boundary conditions (no moving walls): mixing runs ns2d_fast2");
   // dx == dy (every reference configuration): one multiply per cell instead of two
   if (a.cx == a.cy) return launch_fast_eq<real, NX, NY, R, KIND, true, GF>(a, batch, s);
   return launch_fast_eq<real, NX, NY, R, KIND, false, GF>(a, batch, s);

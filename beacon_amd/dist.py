@@ -84,15 +84,19 @@ class ShardedVecEnv(object):
         obs, rwd, done, trunc, _ = env.step(actions_global_or_None_on_other_ranks)
 
     Envs that draw inlet noise on the device (burgers, shkadov) are re-seeded with seed + global replica
-    offset, so that replica i of different ranks does not receive the same noise stream."""
+    offset when the batch is sharded, so that replica i of different ranks does not receive the same noise
+    stream; `seed` defaults to the seed the env itself was constructed with (VecBurgers(seed=...)), and an
+    unsharded env (world size 1) keeps its generator untouched."""
 
-    def __init__(self, local_env, group=None, seed=0):
+    def __init__(self, local_env, group=None, seed=None):
         self.env = local_env
         self.sh = ReplicaSharder(local_env.batch, group)
         self.global_batch = self.sh.global_batch
         self.lo, self.hi = shard_bounds(self.global_batch, self.sh.world, self.sh.rank)
-        if getattr(local_env, "gen", None) is not None:
-            local_env.gen.manual_seed(int(seed) + self.lo)
+        self.status = None
+        if getattr(local_env, "gen", None) is not None and (self.sh.world > 1 or seed is not None):
+            base = int(getattr(local_env, "seed", 0) if seed is None else seed)
+            local_env.gen.manual_seed(base + self.lo)
 
     def _like_actions(self):
         e = self.env
@@ -125,8 +129,9 @@ class ShardedVecEnv(object):
         return obs, rwd, done, trunc, None
 
     def gather_status(self):
-        """Status words of the last step() on rank 0 (they travel with the packed outputs)."""
-        return getattr(self, "status", None)
+        """Status words [B_global] of the last step() -- NOT a collective: they travelled with that step's packed
+        outputs, so this returns rank 0's cached copy; None before the first step() and on every other rank."""
+        return self.status
 
     def close(self):
         self.env.close()

@@ -13,6 +13,7 @@ import fcntl
 import hashlib
 import os
 import subprocess
+import warnings
 
 from . import build as _build
 
@@ -44,6 +45,8 @@ def choose(nx, ny, f64, kind):
     esz = 8 if f64 else 4
     if nx < 6 or ny < 4:
         return None
+    if ny <= 64 and kind != 0:
+        return None          # ns2d_fast_impl.h (one row per lane) implements the rayleigh boundary conditions only
     if ny <= 64:
         for nw, rmax in ((8, 16 if f64 else 26), (12, 18), (16, 12), (10, 20), (6, 26), (5, 26), (4, 26), (3, 26), (2, 26)):
             if f64 and nw > 8:
@@ -57,8 +60,7 @@ def choose(nx, ny, f64, kind):
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
         return None
     if ny <= 128:
-        # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); mixing only (KIND 1 has no buoyancy
-        # read of S in the predictor that the scratch would slow down further -- and it is the case the reference has)
+        # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); rayleigh and mixing alike
         for nw, rmax in (((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
             r = -(-nx // nw)
             rl = nx - (nw - 1) * r
@@ -98,21 +100,32 @@ def build_plugin(nx, ny, f64, kind, verbose=False):
     cc = _build.hipcc()
     if cc is None or os.environ.get("BEACON_NO_BUILD") == "1":
         return None
-    os.makedirs(JIT_DIR, exist_ok=True)
-    with open(os.path.join(JIT_DIR, ".lock"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)              # N ranks of one node asking for the same grid
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    try:
+        os.makedirs(JIT_DIR, exist_ok=True)
+        with open(os.path.join(JIT_DIR, ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)          # N ranks of one node asking for the same grid
+            try:
+                if os.path.exists(path):
+                    return path
+                cmd = ([cc] + _build.FLAGS + _build.FILE_FLAGS.get("ns2d_fast.hip", []) +
+                       ["-D%s=%s" % kv for kv in sorted(defs.items())] + ["-I", _build.INC, "-shared", JIT_SRC, "-o", tmp])
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                os.replace(tmp, path)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+    except (OSError, subprocess.CalledProcessError) as e:
+        # a read-only package directory, a full disk or a compiler error: the env keeps the generic kernel
+        # (still on the GPU, only slower) instead of failing in its constructor
+        warnings.warn("beacon_amd.jit: no register-resident kernel for %dx%d (%s); the generic kernel stays selected"
+                      % (nx, ny, e))
         try:
-            if os.path.exists(path):
-                return path
-            tmp = "%s.tmp%d" % (path, os.getpid())
-            cmd = ([cc] + _build.FLAGS + _build.FILE_FLAGS.get("ns2d_fast.hip", []) +
-                   ["-D%s=%s" % kv for kv in sorted(defs.items())] + ["-I", _build.INC, "-shared", JIT_SRC, "-o", tmp])
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            os.replace(tmp, path)
-        finally:
-            fcntl.flock(lock, fcntl.LOCK_UN)
+            os.remove(tmp)
+        except OSError:
+            pass
+        return None
     return path
 
 
@@ -132,7 +145,11 @@ def plugin_for(nx, ny, f64, kind):
     key = (nx, ny, bool(f64), kind)
     if key not in _LOADED:
         path = build_plugin(nx, ny, f64, kind)
-        p = Plugin(path) if path else None
+        try:
+            p = Plugin(path) if path else None
+        except (OSError, AttributeError) as e:        # a truncated or foreign shared object in the cache
+            warnings.warn("beacon_amd.jit: cannot load %s (%s); the generic kernel stays selected" % (path, e))
+            p = None
         if p is not None and p.lds > LDS_BYTES:
             p = None
         _LOADED[key] = p
@@ -150,9 +167,12 @@ def prebuild(grids=None, verbose=False):
     """Compile the plugins of a list of (nx, ny, f64, kind) grids (used by __graft_entry__.build() for the grids the
     tests touch, so that they ship with the tree)."""
     paths = [build_plugin(nx, ny, f64, kind, verbose) for nx, ny, f64, kind in (grids or TEST_GRIDS)]
-    if grids is None and os.path.isdir(JIT_DIR):      # drop plugins of older source states (their hash no longer matches)
+    if os.path.isdir(JIT_DIR):
+        # drop the plugins of older source states of THESE grids (same name up to the hash); plugins that users compiled
+        # on demand for other grids stay (a stale one is merely unused: build_plugin() compiles the current hash next to it)
         keep = {os.path.basename(p) for p in paths if p}
+        stems = {k.rsplit("_", 1)[0] for k in keep}
         for f in os.listdir(JIT_DIR):
-            if f.endswith(".so") and f not in keep:
+            if f.endswith(".so") and f not in keep and f.rsplit("_", 1)[0] in stems:
                 os.remove(os.path.join(JIT_DIR, f))
     return paths

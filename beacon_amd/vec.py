@@ -448,8 +448,9 @@ class VecBurgers(VecEnv):
         super().__init__(batch, device, dtype)
         self.action_space = Box(-1.0, 1.0, (1,))
         self.observation_space = Box(0.0, 1.0, (self.n_obs_pts,))
+        self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed)
+        self.gen.manual_seed(self.seed)
 
     def _derive(self, u_target=0.5, amp=10.0, sigma=0.1, ctrl_pos=1.0, L=2.0, nx=500):
         self.L, self.nx, self.amp, self.sigma, self.u_target = L, nx, amp, sigma, u_target
@@ -502,8 +503,9 @@ class VecShkadov(VecEnv):
         super().__init__(batch, device, dtype)
         self.action_space = Box(-1.0, 1.0, (n_jets,))
         self.observation_space = Box(-1.0, 1.0, (self.n_obs * n_jets,))
+        self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed)
+        self.gen.manual_seed(self.seed)
         self._init_dev = None
         if self._init_np is not None:
             self._init_dev = self._real(np.ascontiguousarray(self._init_np[:, :self.nx]), (2, self.nx))

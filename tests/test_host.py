@@ -169,6 +169,9 @@ class Env:                                               # CPU stand-in with the
 
 senv = ShardedVecEnv(Env(), seed=5)
 assert senv.env.gen.initial_seed() == 5 + lo           # noise streams differ per rank
+assert senv.gather_status() is None                    # cached copy of the last step's words: none yet
+e9 = Env(); e9.seed = 9; e9.gen.manual_seed(9)
+assert ShardedVecEnv(e9).env.gen.initial_seed() == 9 + lo   # default: the env's own seed, offset by the shard
 o, _ = senv.reset()
 assert (o is None) == (rank != 0) and (rank != 0 or o.shape == (2 * B, 3))
 o, r, d, t, _ = senv.step(full if rank == 0 else None)
