@@ -52,6 +52,10 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --stub)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; nccl needs one device per rank)")
+    ap.add_argument("--dist-timeout", type=float, default=300.0,
+                    help="seconds a rank waits in the rendezvous / a collective before it gives up (init_process_group timeout)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1, --scaling weak: skip the extra strong-scaling loop (global batch sharded) reported under `strong`")
     ap.add_argument("--stub", action="store_true",
                     help="CPU stand-in env (no GPU, no kernels): exercises launcher, sharding and gather only; "
                          "its line is marked data=stub and is not a measurement")
@@ -69,17 +73,44 @@ def free_port():
     return port
 
 
-def launch_children(n, argv):
+def launch_children(n, argv, poll_s=0.1, grace_s=5.0):
+    """Start one fresh process per rank and watch ALL of them: the first rank that ends with a non-zero code takes
+    the others down (SIGTERM, SIGKILL after `grace_s`) and the parent returns that code at once -- a rank that died
+    at init_process_group must not leave its peers waiting in the rendezvous until somebody's timeout.  The children
+    are the exact PIDs started here (never a pattern), and they are ended on every way out of this function."""
     port = free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        rc = 0
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(poll_s)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = abs(code) or 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n"
+                                     % (procs.index(p), code))
+                    break
+        return rc
+    finally:
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_end = time.time() + grace_s
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -319,12 +350,18 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = "cuda:%d" % local_rank
+    fault = os.environ.get("BENCH_FAULT_RANK")          # test hook: this rank dies before the rendezvous
+    if fault is not None and int(fault) == rank:
+        sys.stderr.write("bench.py: injected fault on rank %d\n" % rank)
+        os._exit(3)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if args.stub or args.backend != "nccl":
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
         else:
-            dist.init_process_group(args.backend, device_id=torch.device(dev))
+            dist.init_process_group(args.backend, timeout=tmo, device_id=torch.device(dev))
 
     if args.scaling == "strong":
         if args.batch % world:
@@ -336,16 +373,21 @@ def main():
     K, W = args.steps, args.warmup
     L, H = 2.56, 1.28
     init = None
-    if args.stub:
-        env = StubEnv(B)
-    else:
+    if not args.stub:
         from beacon_amd import vec as V
         init = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))["fields"]
-        env = V.VecRayleigh(B, dev, args.dtype, init, L=L, H=H)
+
+    def make_env(nrep):
+        if args.stub:
+            return StubEnv(nrep)
+        e = V.VecRayleigh(nrep, dev, args.dtype, init, L=L, H=H)
         if args.variant >= 0:
-            env.set_variant(args.variant)
+            e.set_variant(args.variant)
         if args.sched >= 0:
-            env.set_sched(args.sched)
+            e.set_sched(args.sched)
+        return e
+
+    env = make_env(B)
     senv = ShardedVecEnv(env)
     # one global action stream, every rank takes the slice of its replicas (weak: a longer stream)
     acts_g = np.random.default_rng(1234).uniform(-1.0, 1.0, (W + K, Bg, env.n_sgts))
@@ -391,6 +433,32 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
+
+    # N > 1, weak scaling: one more short timed loop with the GLOBAL batch of --batch replicas sharded over the ranks,
+    # so that one invocation carries both readings of "batch=512 at 1/2/4/8 GPUs" (same barriers, max over ranks)
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong and args.batch % world == 0:
+        Bs, Ks, Ws = args.batch // world, min(K, 5), 1
+        env_s = make_env(Bs)
+        senv_s = ShardedVecEnv(env_s)
+        a_s = np.random.default_rng(1234).uniform(-1.0, 1.0, (Ws + Ks, args.batch, env_s.n_sgts))[:, senv_s.lo:senv_s.hi]
+        a_s = torch.as_tensor(a_s, dtype=env_s.tdtype, device=dev)
+        senv_s.reset()
+        for k in range(Ws):
+            senv_s.step(a_s[k], scattered=True)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(Ks):
+            env_s.step(a_s[Ws + k])
+            senv_s._gather()
+        sync()
+        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        env_s.check_status()
+        strong = {"scaling": "strong", "global_batch": args.batch, "replicas_per_gpu": Bs, "steps": Ks, "warmup": Ws,
+                  "ms_per_step": 1e3 * float(ts.item()) / Ks, "value": args.batch * Ks / float(ts.item()),
+                  "unit": "env steps/s"}
+        env_s.close()
 
     if rank == 0:
         kern_ms = [s.elapsed_time(e) for s, e in ev] if use_ev else [1e3 * elapsed / K] * K
@@ -448,6 +516,8 @@ def main():
                        "kernel": kname},
             "roofline": roof,
         }
+        if strong is not None:
+            out["strong"] = strong
         if world == 1 and not args.no_cpu and not args.stub:
             out["cpu_baseline"] = cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H))
         if world == 1 and not args.no_secondary and not args.stub:

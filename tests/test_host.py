@@ -7,6 +7,7 @@ import json
 import os
 import re
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -213,6 +214,28 @@ def test_bench_self_launch_and_scalings_on_cpu_stub():
         assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["data"] == "stub" and d["steps"] == 3
         assert d["config"]["global_batch"] == glob and ("%d replicas per GPU" % per_gpu) in d["config"]["workload"]
         assert abs(d["value"] - glob * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+        if scaling == "weak":      # the weak line also carries the strong-scaling reading of the same --batch
+            st = d["strong"]
+            assert st["global_batch"] == 16 and st["replicas_per_gpu"] == 8 and st["steps"] == 3 and st["value"] > 0
+        else:
+            assert "strong" not in d
+
+
+def test_bench_launcher_stops_every_rank_when_one_dies():
+    """A rank that dies before the rendezvous (BENCH_FAULT_RANK: os._exit(3) in front of init_process_group) must not
+    leave its peer waiting there: the self-launching parent polls all children, terminates the survivors and exits
+    non-zero within seconds -- far below the rendezvous timeout, which is set to 120 s here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_FAULT_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--stub", "--backend", "gloo", "--dist-timeout", "120"],
+                       env=env, capture_output=True, text=True, timeout=100)
+    dt = time.time() - t0
+    assert r.returncode != 0, r.stdout + r.stderr
+    assert dt < 60, dt
+    assert "rank 1 exited with code 3" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no line from a half-dead job
 
 
 def test_vortex_host_env_matches_reference_episodes():
