@@ -73,9 +73,9 @@ struct NS2DEnv : bcn_env_s {
     status_int = static_cast<int32_t*>(statusbuf.p);
     if ((rc = orderbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
     a.order_out = static_cast<int32_t*>(orderbuf.p);
-    {   // [ SchedCtl + progress[B] | pad to 16 | cyc[B][2] ]: zeroed by one memset per step
+    {   // [ SchedCtl + progress[B] | pad to 16 | cyc[B][4] ]: zeroed by one memset per step
       const size_t ctl = (128 + (size_t)batch * sizeof(uint32_t) + 15) / 16 * 16;
-      a.sched_bytes = ctl + (size_t)batch * 2 * sizeof(unsigned long long);
+      a.sched_bytes = ctl + (size_t)batch * 4 * sizeof(unsigned long long);
       if ((rc = schedbuf.alloc(a.sched_bytes))) return rc;
       BCN_HIP(hipMemset(schedbuf.p, 0, a.sched_bytes));
       a.sched_ctl = schedbuf.p;
@@ -88,7 +88,9 @@ struct NS2DEnv : bcn_env_s {
       a.fscr = static_cast<real*>(fscrbuf.p);
     }
     variant = fast_ok ? 1 : 0;
-    a.conv_plan = sizeof(real) == 4 ? 2 : 1;   // ns2d_fast.hip: float64 keeps the proven plan (exact stop sweep)
+    // float64: the proven plan (exactly the reference's stop sweep); float32: the extrapolating plan, guarded -- a stop it
+    // did not foresee is repeated under the proven plan (ns2d_fast_impl.h)
+    a.conv_plan = sizeof(real) == 4 ? 3 : 1;
     if (const char* e = getenv("BCN_CONV_PLAN")) a.conv_plan = atoi(e);
     // rayleigh float32: consecutive timesteps never differed by more than 30 % (611 000 solves); mixing's do; the float64
     // kernels are built without the jump (ns2d_fast_impl.h)
@@ -127,13 +129,14 @@ struct NS2DEnv : bcn_env_s {
     return BCN_OK;
   }
   int set_option(const char* name, int value) override {
-    if (!strcmp(name, "conv_plan") && value >= 0 && value <= 2) { a.conv_plan = value; return BCN_OK; }
+    if (!strcmp(name, "conv_plan") && value >= 0 && value <= 3) { a.conv_plan = value; return BCN_OK; }
+    if (!strcmp(name, "plan_overshoot") && value >= 0 && value <= 64) { a.plan_overshoot = value; return BCN_OK; }
     if (!strcmp(name, "verify_conv")) { a.verify_conv = value ? 1 : 0; return BCN_OK; }
     if (!strcmp(name, "spec_start") && value >= 0 && value <= 16) { a.spec_start = value; return BCN_OK; }
     return bcn_env_s::set_option(name, value);
   }
   int get_counters(uint64_t* host, hipStream_t s) override {
-    BCN_HIP(hipMemcpyAsync(host, a.cyc, (size_t)batch * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    BCN_HIP(hipMemcpyAsync(host, a.cyc, (size_t)batch * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     BCN_HIP(hipStreamSynchronize(s));
     return BCN_OK;
   }

@@ -48,10 +48,11 @@ struct NS2DArgs {
   int32_t* order_out;       // rank kernel output
   int32_t* sweeps_int;      // handle-owned [B][ndt_act] when the caller passes no sweeps buffer
   void* sched_ctl;          // handle-owned control block of the ticketed chunk scheduler (64 + 4B bytes), followed by
-  unsigned long long* cyc;  // [B][2] shader-clock cycles of the last step: inside the Jacobi loop / whole replica (bcn_get_counters)
+  unsigned long long* cyc;  // [B][4] of the last step: shader-clock cycles inside the Jacobi loop / in the whole replica, late stops, repeated timesteps (bcn_get_counters)
   size_t sched_bytes;       // bytes of sched_ctl + cyc: zeroed by one memset in front of every step launch
   int sched_q;              // timesteps per chunk
-  int conv_plan = 1;        // which Jacobi sweeps evaluate the residual: 0 all, 1 proven skips only, 2 + extrapolated (ns2d_fast.hip)
+  int conv_plan = 1;        // which Jacobi sweeps evaluate the residual: 0 all, 1 proven skips only, 2 + extrapolated, 3 = 2 with unverified stops repeated under 1 (ns2d_fast_impl.h)
+  int plan_overshoot = 0;   // TEST HOOK: sweeps added to every skip of the extrapolating plan (provokes late stops: tests of conv_plan 3)
   int spec_start = 0;       // first evaluation of a solve at spec_start/8 of the previous timestep's sweep count (0: at sweep 1): ns2d_fast_impl.h
   int verify_conv = 0;      // 1: evaluate the Jacobi residual after every sweep and flag BCN_ST_PLAN if the evaluation plan
                             //    of the register-resident kernels would have skipped a sweep that passes the test (BCN_VERIFY_CONV=1)

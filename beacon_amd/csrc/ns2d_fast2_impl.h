@@ -296,6 +296,10 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   if (!first_chunk) status = A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
   const unsigned long long cyc_u0 = __builtin_amdgcn_s_memtime();
   unsigned long long cyc_j = 0;
+  // red[21]: solves whose stop sweep the extrapolating plan could not verify ("late stops"); red[22]: solves repeated
+  // under the proven plan (conv_plan 3): see the end of the Jacobi loop.  Written and read by thread 0 only.
+  real* const guard = red + 21;
+  if (tid == 0) { guard[0] = 0; guard[1] = 0; }
   for (int it = it_begin; it < it_end && status == 0; it++) {
     // fields in the global scratch: keep hipcc from hoisting the (64-bit) addresses of a whole timestep out of the loop
     if (GF) asm volatile("" : "+v"(j0));
@@ -499,14 +503,20 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     // The residual is evaluated only on the sweeps that can pass the test (A.conv_plan, see ns2d_fast.hip); a sweep
     // that evaluates it does so behind its own barrier, with the arithmetic the fused form had.
     real phA[2][RW], phB[2][RW];
+    real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
+    real hW0r, hW1r, hE0r, hE1r;
+    int itp;
+    bool finalB;
+    // the evaluation plan of this solve: conv_plan 3 is plan 2 whose unverified stops are repeated under plan 1 (below)
+    int plan = (A.conv_plan == 3) ? 2 : A.conv_plan;
+    for (;;) {   // the solve (once; twice when conv_plan 3 repeats it: u*, v* and the rhs are untouched by the sweeps)
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int k = 0; k < RW; k++) phA[a][k] = 0;
-    real hW0 = 0, hW1 = 0, hE0 = 0, hE1 = 0;
-    real hW0r = 0, hW1r = 0, hE0r = 0, hE1r = 0;
-    int itp = 0;
-    bool finalB = false;
+    hW0r = 0; hW1r = 0; hE0r = 0; hE1r = 0;
+    itp = 0;
+    finalB = false;
     int k_prev = -1;
     float l2u_prev = 0, l2w_prev = 0;
     int skip_left = 0;
@@ -571,14 +581,14 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       const real part = pI + (cW0 * dW0 + cW1 * dW1) + (cE0 * dE0 + cE1 * dE1);                      \
       const real tot63 = wave_sum_lane63<real>(part);                                                \
       if (lane == 63) errp[xb * 32 + w] = tot63;                                                     \
-      if (A.conv_plan == 1) {   /* unweighted interior norm (lanes past the top row pair hold zeros) */ \
+      if (plan == 1) {   /* unweighted interior norm (lanes past the top row pair hold zeros) */ \
         const real totu63 = wave_sum_lane63<real>((acc0 + acc1) + (dW0 + dW1) + (dE0 + dE1));        \
         if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                             \
       }                                                                                              \
       __syncthreads();                                                                               \
       itp++;                                                                                         \
       const real eW = errp[xb * 32 + (lane & 15)];                                                   \
-      const real eU = (A.conv_plan == 1) ? errp[xb * 32 + 16 + (lane & 15)] : real(0);               \
+      const real eU = (plan == 1) ? errp[xb * 32 + 16 + (lane & 15)] : real(0);               \
       BCN_HALO_READS                                                                                 \
       const real err = read_lane(row16_sum<real>(eW), 15);                                           \
       if (!(err > A.tol)) {                                                                          \
@@ -589,21 +599,21 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       n = 0;                                                                                         \
       if (skip_left > 0) {                                                                           \
         skip_left--;                                                                                 \
-      } else if (A.conv_plan > 0) {                                                                  \
+      } else if (plan > 0) {                                                                  \
         const float l2w = __log2f((float)err);                                                       \
         float l2u = 0;                                                                               \
-        if (A.conv_plan == 1) l2u = __log2f((float)read_lane(row16_sum<real>(eU), 15));              \
+        if (plan == 1) l2u = __log2f((float)read_lane(row16_sum<real>(eU), 15));              \
         int j = 0;                                                                                   \
         if (k_prev >= 0) {                                                                           \
           const float rg = 1.f / (float)(itp - 1 - k_prev);                                          \
-          if (A.conv_plan == 1) {                                                                    \
+          if (plan == 1) {                                                                    \
             const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;                       \
             if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX;   \
           } else {                                                                                   \
             const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;                       \
             int jw = 0;                                                                              \
             if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX;  \
-            j = jw - 1 - (jw >> 4);                                                                  \
+            j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                                                  \
             j = j > 0 ? j : 0;                                                                       \
           }                                                                                          \
         }                                                                                            \
@@ -633,6 +643,14 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #undef BCN_HALO_READS
 #undef BCN_CELLS
 #undef BCN_CELL
+    // guard of the extrapolating plan, as in ns2d_fast_impl.h: a passing evaluation that directly follows skipped sweeps
+    // is a stop the plan did not foresee ("late stop": counted; conv_plan 3 repeats the solve under the proven plan)
+    const bool late = plan >= 2 && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
+    if (late && tid == 0) guard[0] += 1;
+    if (!(late && A.conv_plan == 3)) break;
+    plan = 1;
+    if (tid == 0) guard[1] += 1;
+    }
 #undef NB
     if (finalB) {
 #pragma unroll
@@ -765,8 +783,10 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     A.status[b] = status;
   }
   if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
-    A.cyc[2 * (size_t)b] += cyc_j;
-    A.cyc[2 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
+    A.cyc[4 * (size_t)b] += cyc_j;
+    A.cyc[4 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
+    A.cyc[4 * (size_t)b + 2] += (unsigned long long)guard[0];
+    A.cyc[4 * (size_t)b + 3] += (unsigned long long)guard[1];
   }
 #ifdef BCN_STAMP   // diagnostic build only: cycles per timestep of each phase over the first obs entries
   __syncthreads();

@@ -338,6 +338,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #else
   if (tid == 0) prev_sweeps[0] = 0;
 #endif
+  // prev_sweeps[1]: this timestep's solve runs under the proven plan (a repeat, conv_plan 3); [2]: solves whose stop sweep the
+  // extrapolating plan could not verify ("late stops"); [3]: timesteps repeated (speculative jump too far, or conv_plan 3)
+  if (tid == 0) { prev_sweeps[1] = 0; prev_sweeps[2] = 0; prev_sweeps[3] = 0; }
   for (int it = it_begin; it < it_end && status == 0; it++) {
     if (GF) asm volatile("" : "+v"(j));
     // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
@@ -512,6 +515,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #endif
     const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
     constexpr int JMAX = 256;
+    // the evaluation plan of THIS solve: conv_plan 3 is plan 2 whose unverified stops are repeated under plan 1
+    const int plan = (A.conv_plan == 3) ? (__builtin_amdgcn_readfirstlane((int)prev_sweeps[1]) != 0 ? 1 : 2) : A.conv_plan;
     // all cells of one sweep; the two strip-edge cells come last (their halos were requested behind the previous
     // barrier) and go to the exchange buffer at once, in front of whatever else the sweep still has to do
 #define BCN_CELLS(SRC, DST)                                                                  \
@@ -583,7 +588,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
       const real tot63 = wave_sum_lane63<real>(part);                                        \
       if (lane == 63) errp[xb * 32 + w] = tot63;                                             \
-      if (A.conv_plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
+      if (plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
         const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + dl * dl);                  \
         if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                     \
       }                                                                                      \
@@ -596,7 +601,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real esum = row16_sum<real>(epart);                                              \
       const real err = read_lane(esum, 15);                                                  \
       /* behind the speculative jump the proven plan also needs the unweighted norm above its threshold */ \
-      const bool amb = SPEC && skip_left == -2 && A.conv_plan == 1 && !(read_lane(esum, 31) > A.tol * real(1.02)); \
+      const bool amb = SPEC && skip_left == -2 && plan == 1 && !(read_lane(esum, 31) > A.tol * real(1.02)); \
       if (!(err > A.tol) || amb) {                                                           \
         if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
         if (SPEC) skip_left = skip_left == -2 ? -1 : 0;                                      \
@@ -607,20 +612,20 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       n = 0;                                                                                 \
       if (skip_left > 0) {                                                                   \
         skip_left--;                                                                         \
-      } else if (A.conv_plan > 0) {   /* plan the next evaluation (see above) */             \
-        const float l2u = (A.conv_plan == 1) ? __log2f((float)read_lane(esum, 31)) : 0.f; \
+      } else if (plan > 0) {   /* plan the next evaluation (see above) */             \
+        const float l2u = (plan == 1) ? __log2f((float)read_lane(esum, 31)) : 0.f; \
         const float l2w = __log2f((float)err);                                               \
         int j = 0;                                                                           \
         if (k_prev >= 0) {                                                                   \
           const float rg = 1.f / (float)(itp - 1 - k_prev);                                  \
-          if (A.conv_plan == 1) {                                                            \
+          if (plan == 1) {                                                            \
             const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;               \
             if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
           } else {                                                                           \
             const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;               \
             int jw = 0;                                                                      \
             if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
-            j = jw - 1 - (jw >> 4);                                                          \
+            j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                                          \
             j = j > 0 ? j : 0;                                                               \
           }                                                                                  \
         }                                                                                    \
@@ -639,7 +644,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         BCN_FAST(phB, phA)
         n = (n - 1) & ~1;
       }
-      if (SPEC && itp == 2 && A.spec_start > 0 && A.conv_plan > 0 && !A.verify_conv) {   // first pass: the speculative jump
+      if (SPEC && itp == 2 && A.spec_start > 0 && plan > 0 && !A.verify_conv) {   // first pass: the speculative jump
         const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
         const int ns = ((prev * A.spec_start) >> 3) - 2;
         if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }
@@ -661,13 +666,22 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #undef BCN_FAST
 #undef BCN_SWEEP_END
 #undef BCN_CELLS
-    if constexpr (SPEC) {
-      if (skip_left == -1) {   // the speculative jump went too far (cold): this timestep again -- BC, predictor and rhs
-        if (tid == 0) prev_sweeps[0] = 0;   // recompute the same values from the unchanged fields -- and its solve without a guess
+    {
+      // Guard of the extrapolating plan (conv_plan 2, 3).  A stop at sweep s is the reference's stop sweep when sweep s - 1
+      // was evaluated (and failed); when the passing evaluation directly follows SKIPPED sweeps the plan's own estimate was
+      // wrong -- the decay accelerated -- and an earlier sweep may have passed as well: a "late stop", counted per replica
+      // (bcn_get_counters).  conv_plan 3 repeats such a timestep under the proven plan 1, as a jump that went too far
+      // (skip_left == -1) repeats it without the guess: BC, predictor and rhs recompute the same values from the
+      // unchanged fields.
+      const bool toofar = SPEC && skip_left == -1;
+      const bool late = plan >= 2 && !toofar && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
+      if (late && tid == 0) prev_sweeps[2] += 1;
+      if (toofar || (late && A.conv_plan == 3)) {
+        if (tid == 0) { prev_sweeps[0] = 0; prev_sweeps[1] = toofar ? real(0) : real(1); prev_sweeps[3] += 1; }
         it--;
         continue;
       }
-      if (tid == 0) prev_sweeps[0] = (real)itp;
+      if (tid == 0) { prev_sweeps[0] = SPEC ? (real)itp : real(0); prev_sweeps[1] = 0; }
     }
     if (finalB) {
 #pragma unroll
@@ -778,8 +792,10 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     A.status[b] = status;
   }
   if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
-    A.cyc[2 * (size_t)b] += cyc_j;
-    A.cyc[2 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
+    A.cyc[4 * (size_t)b] += cyc_j;
+    A.cyc[4 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
+    A.cyc[4 * (size_t)b + 2] += (unsigned long long)prev_sweeps[2];
+    A.cyc[4 * (size_t)b + 3] += (unsigned long long)prev_sweeps[3];
   }
 }
 

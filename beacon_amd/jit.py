@@ -103,8 +103,8 @@ def build_plugin(nx, ny, f64, kind, verbose=False):
     tmp = "%s.tmp%d" % (path, os.getpid())
     try:
         os.makedirs(JIT_DIR, exist_ok=True)
-        with open(os.path.join(JIT_DIR, ".lock"), "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)          # N ranks of one node asking for the same grid
+        with open(path + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)          # N ranks of one node asking for the same grid (one lock per plugin)
             try:
                 if os.path.exists(path):
                     return path
@@ -166,7 +166,9 @@ TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 6
 def prebuild(grids=None, verbose=False):
     """Compile the plugins of a list of (nx, ny, f64, kind) grids (used by __graft_entry__.build() for the grids the
     tests touch, so that they ship with the tree)."""
-    paths = [build_plugin(nx, ny, f64, kind, verbose) for nx, ny, f64, kind in (grids or TEST_GRIDS)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("BEACON_JIT_JOBS", "4"))) as ex:
+        paths = list(ex.map(lambda g: build_plugin(g[0], g[1], g[2], g[3], verbose), grids or TEST_GRIDS))
     if os.path.isdir(JIT_DIR):
         # drop the plugins of older source states of THESE grids (same name up to the hash); plugins that users compiled
         # on demand for other grids stay (a stale one is merely unused: build_plugin() compiles the current hash next to it)
@@ -175,4 +177,9 @@ def prebuild(grids=None, verbose=False):
         for f in os.listdir(JIT_DIR):
             if f.endswith(".so") and f not in keep and f.rsplit("_", 1)[0] in stems:
                 os.remove(os.path.join(JIT_DIR, f))
+            elif f.endswith(".lock"):
+                try:
+                    os.remove(os.path.join(JIT_DIR, f))
+                except OSError:
+                    pass
     return paths

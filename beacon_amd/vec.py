@@ -175,10 +175,11 @@ class VecEnv(object):
         _lib.check(self.lib.bcn_set_option(self.h, name.encode(), int(value)))
 
     def get_counters(self):
-        """uint64 [B, 2]: shader cycles of the last step inside the Jacobi loop / in the whole replica."""
-        buf = (C.c_uint64 * (2 * self.batch))()
+        """uint64 [B, 4] of the last step, per replica: shader cycles inside the Jacobi loop / in the whole replica, late
+        stops of the extrapolating residual plan, repeated timesteps (include/beacon_hip.h: bcn_get_counters)."""
+        buf = (C.c_uint64 * (4 * self.batch))()
         _lib.check(self.lib.bcn_get_counters(self.h, buf, self._stream()))
-        return np.frombuffer(buf, dtype=np.uint64).reshape(self.batch, 2).copy()
+        return np.frombuffer(buf, dtype=np.uint64).reshape(self.batch, 4).copy()
 
     @property
     def kernel_name(self):
@@ -246,11 +247,16 @@ class VecEnv(object):
         return self.reset(mask=self._done_mask)
 
     def warmup(self, n_steps, actions=None):
-        """Equivalent of the reference's init.py generators: n uncontrolled action steps
-        (zero / repeated action), e.g. to develop the flow from rest on a grid that ships no
-        init_field.dat.  Episode counters are reset afterwards."""
+        """Equivalent of the reference's init.py generators (rayleigh/init.py:13-28): n uncontrolled action steps
+        (zero / repeated action), e.g. to develop the flow on a grid that ships no init_field.dat.  The per-step
+        rewards are kept in `self.warmup_rwd` [n_steps, B] (rayleigh: minus the Nusselt history the reference's
+        generator plots); episode counters are reset afterwards."""
+        rw = []
         for _ in range(int(n_steps)):
             self._step(actions, None)
+            rw.append(self.rwd.clone())
+        self.warmup_rwd = torch.stack(rw) if rw else torch.empty((0, self.batch), dtype=self.tdtype, device=self.device)
+        self.check_status()
         self.set_stp(0)
         return self.get_state()
 
@@ -355,6 +361,35 @@ class VecRayleigh(VecEnv):
 
     def state_shape(self):
         return (4, self.ny + 2, self.nx + 2)
+
+    def perturbed_conduction_state(self, seed=2024):
+        """Start state of a warm-up on a grid without an init file, [4, nx+2, ny+2] in the reference's [i, j] layout:
+        u = v = p = 0, T = the conduction profile plus five seeded long-wave perturbations of amplitude <= 0.02 (from
+        the reference's all-zero start, rayleigh/init.py:13, an exactly x-uniform state never leaves pure conduction)."""
+        rng = np.random.default_rng(seed)
+        xm = (np.arange(self.nx + 2) - 0.5) * self.dx
+        ym = (np.arange(self.ny + 2) - 0.5) * self.dy
+        X, Y = np.meshgrid(xm, ym, indexing="ij")
+        T = self.Th + (self.Tc - self.Th) * Y / self.H
+        for k in range(1, 6):
+            T += 0.02 * rng.uniform(-1, 1) * np.sin(np.pi * Y / self.H) * np.cos(k * np.pi * X / self.L + rng.uniform(0, 6.28))
+        T[:, 0] = 0.0
+        T[:, -1] = 0.0
+        st = np.zeros((4, self.nx + 2, self.ny + 2))
+        st[3] = T
+        return st
+
+    def develop(self, n_steps=None, seed=2024):
+        """The reference's init.py on the device (rayleigh/init.py:13-28: n_warmup uncontrolled action steps, then
+        dump): every replica starts from perturbed_conduction_state(seed) and takes n_steps (default n_warmup = 100)
+        zero-action steps.  Returns the developed fields of replica 0 as [4, nx+2, ny+2] float64 in the reference's
+        layout -- what VecRayleigh(init_fields=...) takes -- and keeps minus the Nusselt history in `warmup_rwd`."""
+        st0 = self.perturbed_conduction_state(seed)
+        self.reset()
+        self.set_state(np.tile(np.ascontiguousarray(st0.transpose(0, 2, 1))[None], (self.batch, 1, 1, 1)))
+        zero = torch.zeros((self.batch, self.n_sgts), dtype=self.tdtype, device=self.device)
+        st = self.warmup(self.n_warmup if n_steps is None else n_steps, zero)
+        return np.ascontiguousarray(st[0].double().cpu().numpy().transpose(0, 2, 1))
 
     def _reset(self):
         _lib.check(self.lib.bcn_rayleigh_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))

@@ -52,6 +52,11 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --stub)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; nccl needs one device per rank)")
+    ap.add_argument("--L", type=float, default=2.56, help="domain length (nx = 50 L; rayleigh.py:26)")
+    ap.add_argument("--H", type=float, default=1.28, help="domain height (ny = 50 H; rayleigh.py:27)")
+    ap.add_argument("--gen-init", action="store_true",
+                    help="develop the initial state on the GPU (VecRayleigh.develop: rayleigh/init.py's 100 uncontrolled steps, "
+                         "float64) instead of loading the CPU-made fixture; implied for any grid other than 128x64")
     ap.add_argument("--dist-timeout", type=float, default=300.0,
                     help="seconds a rank waits in the rendezvous / a collective before it gives up (init_process_group timeout)")
     ap.add_argument("--no-strong", action="store_true",
@@ -219,14 +224,14 @@ class StubEnv(object):
 
     def get_counters(self):
         import numpy as np
-        return np.ones((self.batch, 2), dtype=np.uint64)
+        return np.ones((self.batch, 4), dtype=np.uint64)
 
     def close(self):
         pass
 
 
 # ------------------------------------------------------------------------------------------------
-def secondary_lines(dev, quick_steps=4):
+def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4):
     """Other configurations of BASELINE.json on this GPU, one short measurement each (HIP events around
     the launch, inputs resident): value = env steps/s, roofline per SURVEY 8d accounting."""
     import numpy as np
@@ -272,19 +277,41 @@ def secondary_lines(dev, quick_steps=4):
         out.append(d)
 
     rng = np.random.default_rng(7)
-    # rayleigh 128x64 float64 (the reference's arithmetic), B=512
-    z = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))
-    env = V.VecRayleigh(512, dev, "f64", z["fields"], L=2.56, H=1.28)
-    env.reset()
-    acts = torch.as_tensor(rng.uniform(-1, 1, (8, 512, 10)), dtype=env.tdtype, device=dev)
-    k = [0]
+    z = {"fields": head_init}
+    W = head_warm
 
-    def st():
-        env.step(acts[k[0] % 8]); k[0] += 1
-    ms = timed(env, st, quick_steps, warm=1)
-    line("rayleigh-v0 128x64 B=512 float64", env, ms, algorithmic_bytes(128, 64, env.sweeps.cpu().numpy(), 8),
-         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
-    env.close()
+    def headline_variant(name, dtype, opts, note):
+        """The headline workload itself (same initial state, same warm-up and timed action stream) with other solver
+        options / in float64: ms per step over the same `steps` steps."""
+        env = V.VecRayleigh(head_acts.shape[1], dev, dtype, z["fields"], L=head_LH[0], H=head_LH[1])
+        for k_, v_ in opts.items():
+            env.set_option(k_, v_)
+        env.reset()
+        acts = torch.as_tensor(head_acts, dtype=env.tdtype, device=dev)
+        k = [0]
+
+        def st():
+            env.step(acts[k[0]]); k[0] += 1
+        n = acts.shape[0] - W
+        ms = timed(env, st, n, warm=W)
+        c = env.get_counters()
+        line(name, env, ms, algorithmic_bytes(env.nx, env.ny, env.sweeps.cpu().numpy(), 4 if dtype == "f32" else 8),
+             {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean()), "steps": n, "options": opts, "note": note,
+              "late_stops_last_step": int(c[:, 2].sum()), "repeated_timesteps_last_step": int(c[:, 3].sum())})
+        env.close()
+
+    # what the float32 stop rule's shortcuts buy (VERDICT r02 item 1c): the proven plan, the unguarded extrapolation,
+    # no speculative jump -- on the headline workload
+    headline_variant("headline workload, float32, conv_plan=1 (proven stop sweep)", "f32", {"conv_plan": 1},
+                     "residual evaluated on every sweep a proven lower bound of the norm cannot exclude; jump proven too")
+    headline_variant("headline workload, float32, conv_plan=1, spec_start=0", "f32", {"conv_plan": 1, "spec_start": 0},
+                     "proven plan without the speculative jump")
+    headline_variant("headline workload, float32, spec_start=0", "f32", {"spec_start": 0},
+                     "default plan (3: extrapolated, late stops repeated under plan 1) without the speculative jump")
+    headline_variant("headline workload, float32, conv_plan=2 (unguarded)", "f32", {"conv_plan": 2},
+                     "extrapolating plan without the late-stop guard (round 2's default)")
+    # rayleigh 128x64 float64 (the reference's arithmetic), B=512, the headline's own steps
+    headline_variant("headline workload (rayleigh-v0 128x64 B=512) in float64", "f64", {}, "the reference's arithmetic; proven plan (conv_plan 1)")
     # mixing 100x100 B=512 (configs[4])
     env = V.VecMixing(512, dev, "f32")
     env.reset()
@@ -296,6 +323,14 @@ def secondary_lines(dev, quick_steps=4):
     ms = timed(env, st, quick_steps, warm=2)
     line("mixing-v0 100x100 B=512 float32 (configs[4])", env, ms,
          algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 4),
+         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+    env.close()
+    # mixing 100x100 B=512 float64 (the reference's arithmetic)
+    env = V.VecMixing(512, dev, "f64")
+    env.reset()
+    k = [0]
+    ms = timed(env, st, 2, warm=1)
+    line("mixing-v0 100x100 B=512 float64", env, ms, algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 8),
          {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
     env.close()
     # burgers N=512 B=1024 (configs[1]): 12 B per cell per timestep
@@ -371,11 +406,20 @@ def main():
         B = args.batch
     Bg = B * world
     K, W = args.steps, args.warmup
-    L, H = 2.56, 1.28
-    init = None
+    L, H = args.L, args.H
+    init, init_src = None, "stub"
     if not args.stub:
         from beacon_amd import vec as V
-        init = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))["fields"]
+        if args.gen_init or (L, H) != (2.56, 1.28):
+            t_gen = time.perf_counter()
+            genv = V.VecRayleigh(1, dev, "f64", None, L=L, H=H, n_sgts=1)
+            init = genv.develop()                       # every rank develops the same (seeded) state
+            init_src = ("developed on the GPU: %d zero-action steps from the seeded conduction state, float64, %s, %.1f s"
+                        % (genv.n_warmup, genv.kernel_name, time.perf_counter() - t_gen))
+            genv.close()
+        else:
+            init = np.load(os.path.join(ROOT, "tests", "golden", "rayleigh_128x64_init.npz"))["fields"]
+            init_src = "tests/golden/rayleigh_128x64_init.npz (float64 C oracle warm-up)"
 
     def make_env(nrep):
         if args.stub:
@@ -503,26 +547,30 @@ def main():
             binding.update({"achieved": insts / launch_s, "frac": insts / launch_s / VALU_ISSUE_PEAK,
                             "source": "profiles/" + vi["source"]})
         roof["binding"] = binding
-        metric = "aggregate env steps/sec, rayleigh-v0 batch=512%s 128x64" % ("/GPU" if args.scaling == "weak" else " global")
+        metric = "aggregate env steps/sec, rayleigh-v0 batch=%d%s %dx%d" % (args.batch, "/GPU" if args.scaling == "weak" else " global", env.nx, env.ny)
         out = {
             "metric": metric,
             "value": Bg * K / elapsed, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "stub" if args.stub else "synthetic",
-            "config": {"workload": "rayleigh-v0 (BASELINE configs[3]): L=2.56 H=1.28 -> 128x64 MAC grid, "
-                                   "%d replicas per GPU, 200 timesteps per step, Jacobi to tol=1e-8" % B,
+            "config": {"workload": "rayleigh-v0 (BASELINE configs[3]): L=%g H=%g -> %dx%d MAC grid, "
+                                   "%d replicas per GPU, 200 timesteps per step, Jacobi to tol=1e-8" % (L, H, env.nx, env.ny, B),
+                       "initial_state": init_src,
                        "global_batch": Bg, "grid": [env.nx, env.ny], "ndt_act": env.ndt_act,
                        "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world + (" (rehearsal: all ranks on cuda:0)" if args.share_gpu else ""),
                        "kernel": kname},
             "roofline": roof,
         }
+        out["solver"] = {"conv_plan": "3 (float32 default: extrapolated residual plan, late stops repeated under the proven plan)"
+                         if args.dtype == "f32" else "1 (float64 default: proven plan)",
+                         "late_stops_last_step": int(cyc[:, 2].sum()), "repeated_timesteps_last_step": int(cyc[:, 3].sum())}
         if strong is not None:
             out["strong"] = strong
         if world == 1 and not args.no_cpu and not args.stub:
             out["cpu_baseline"] = cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H))
         if world == 1 and not args.no_secondary and not args.stub:
             env.close()
-            out["secondary"] = secondary_lines(dev)
+            out["secondary"] = secondary_lines(dev, acts_np, W, init, (L, H))
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

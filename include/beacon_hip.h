@@ -172,9 +172,13 @@ BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);
  * rayleigh 128x64 f32/f64, 50x50 f32/f64, 100x50 / 150x50 / 200x50 / 100x100 f32; mixing 100x100 f32.
  * Results of the two variants agree to rounding (float64: 1e-9).  Returns the variant actually selected. */
 BCN_API int bcn_set_variant(bcn_env_t h, int variant);
-/* Measurement aid (no reference counterpart): shader-clock cycles the last *_step spent per replica
- * inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463) and in the whole replica (all chunks),
- * uint64[B][2] on the host; zeros for kernels that do not count (generic 2D kernel, 1D envs). */
+/* Measurement aid (no reference counterpart), uint64[B][4] on the host, per replica, of the last *_step (all chunks):
+ *   [0] shader-clock cycles inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463), [1] in the whole replica,
+ *   [2] "late stops": solves whose passing evaluation of the residual directly followed sweeps that the extrapolating
+ *       plan (conv_plan 2 / 3) had skipped -- the plan did not foresee the stop, so an earlier sweep may have passed too,
+ *   [3] timesteps (rayleigh) / solves (two-rows-per-lane kernels) that were repeated: a speculative jump that went too
+ *       far, or conv_plan 3 repeating a late stop under the proven plan.
+ * Zeros for kernels that do not count (generic 2D kernel, 1D envs). */
 BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
 /* Register-resident kernel for a grid that is not built into the library.  The reference takes any L, H
  * (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: 100 L, 100 H); csrc/jit/ns2d_jit.hip is compiled for ONE
@@ -186,13 +190,18 @@ BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_ele
 /* Solver options of the 2D envs (no reference counterpart), by name:
  *   "conv_plan"   which Jacobi sweeps evaluate the residual sum((phi - phin)^2) of rayleigh.py:448-449 / mixing.py:457-458
  *                 in the register-resident kernels: 0 = every sweep, as the reference does; 1 = every sweep that can pass
- *                 the test according to a proven lower bound of the norm (same stop sweep; default for BCN_F64);
- *                 2 = additionally extrapolating the norm's observed decay (default for BCN_F32; see ns2d_fast.hip)
+ *                 the test according to a PROVEN lower bound of the norm (exactly the reference's stop sweep; default for
+ *                 BCN_F64); 2 = additionally extrapolating the decay of the reference's norm, which is observed -- not
+ *                 proven -- never to speed up: should it ever, the solve stops a few sweeps after the reference's stop
+ *                 sweep (inside the float32 tolerance), and bcn_get_counters reports it as a late stop; 3 = plan 2, but a
+ *                 late stop is repeated under plan 1 (default for BCN_F32; see ns2d_fast_impl.h)
+ *   "plan_overshoot" 0..64, TEST HOOK: lengthens every skip of plans 2 / 3 by that many sweeps, so that late stops occur
  *   "verify_conv" 1 = evaluate every sweep anyway and raise BCN_ST_PLAN if a sweep the plan skips passes the test
  *   "spec_start"  0..16: behind the evaluations of sweeps 1 and 2, place the next evaluation at spec_start/8 of the
- *                 previous timestep's sweep count (the norm never increases: if that evaluation does not pass, no
- *                 earlier sweep did; if it does, the timestep is repeated without the guess, so results never depend
- *                 on it).  BCN_F32 rayleigh only (default 6); ignored by BCN_F64 handles and off for mixing
+ *                 previous timestep's sweep count; if that evaluation passes, the timestep is repeated without the guess.
+ *                 Under plan 1 the jump is proven (the unweighted norm never increases and must still exceed the
+ *                 tolerance there); under plans 2 / 3 it relies on the same observed monotonicity of the reference's
+ *                 norm as the plan itself.  BCN_F32 rayleigh only (default 6); ignored by BCN_F64 handles, off for mixing
  * Returns BCN_ERR_ARG for unknown names. */
 BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference

@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O  # noqa: E402
 
 
-def main(n_steps=100, L=2.56, H=1.28, seed=2024):
+def start_state(L=2.56, H=1.28, seed=2024):
+    """(oracle env, T[nx+2, ny+2]): conduction profile plus five seeded long-wave perturbations, T ghosts rows zeroed."""
     e = O.rayleigh(init=False, L=L, H=H, n_sgts=1)
     e.reset_fields()
     c = e.cfg
@@ -29,9 +30,14 @@ def main(n_steps=100, L=2.56, H=1.28, seed=2024):
     T = c.Th + (c.Tc - c.Th) * Y / H
     for k in range(1, 6):
         T += 0.02 * rng.uniform(-1, 1) * np.sin(np.pi * Y / H) * np.cos(k * np.pi * X / L + rng.uniform(0, 6.28))
+    T[:, 0] = 0.0
+    T[:, -1] = 0.0
+    return e, T
+
+
+def main(n_steps=100, L=2.56, H=1.28, seed=2024):
+    e, T = start_state(L, H, seed)
     e.S[:] = T
-    e.S[:, 0] = 0.0
-    e.S[:, -1] = 0.0
     t0 = time.time()
     nus = []
     for k in range(n_steps):

@@ -25,6 +25,7 @@ for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end', s, re.S | re.M):
                 elif op.startswith('ds_'): c['ds'] += 1
                 elif op.startswith('global') or op.startswith('buffer'): c['vmem'] += 1
                 elif 'dpp' in b: c['dpp'] += 1
+                elif op.startswith('v_readlane') or op.startswith('v_writelane'): c['lane'] += 1
                 elif op.startswith('v_mov') or op.startswith('v_accvgpr'): c['v_mov'] += 1
                 elif op.startswith('v_'): c['valu'] += 1
                 elif op.startswith('s_waitcnt'): c['wait'] += 1

@@ -552,6 +552,143 @@ def test_convergence_plan_never_skips_a_passing_sweep():
         assert torch.equal(planned[i][1], literal[j][1]) and torch.equal(planned[i][2], literal[j][2])
 
 
+# workloads of the wider plan checks: name -> (constructor, driver); every driver returns the tensors to compare
+def _plan_workloads():
+    def jit_grid(L, H):
+        def make():
+            env = V.VecRayleigh(6, DEV, "f32", None, L=L, H=H)
+            env.set_ndt_act(30)
+            assert env.set_variant(1) == 1 and getattr(env, "_plugin", None) is not None
+            return env
+
+        def drive(env):
+            x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+            st0 = np.zeros((4, env.nx + 2, env.ny + 2))
+            st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x * L)[:, None] * np.sin(np.pi * y)[None, :]
+            env.reset()
+            env.set_state(np.tile(ref_to_dev(st0)[None], (6, 1, 1, 1)))
+            acts = np.random.default_rng(3).uniform(-1, 1, (2, 6, 10))
+            sw = []
+            for k in range(2):
+                env.step(acts[k])
+                sw.append(env.sweeps.clone())
+            return sw
+        return make, drive
+
+    def ra_sgts(ra, n_sgts):
+        def make():
+            g = golden("rayleigh_default")
+            env = V.VecRayleigh(8, DEV, "f32", _ray_init(g), n_sgts=n_sgts, ra=ra)
+            assert env.set_variant(1) == 1
+            return env
+
+        def drive(env):
+            env.reset()
+            env.step(np.random.default_rng(5).uniform(-1, 1, (8, n_sgts)))
+            return [env.sweeps.clone()]
+        return make, drive
+
+    def mixing_full():
+        def make():
+            return V.VecMixing(512, DEV, "f32")
+
+        def drive(env):
+            env.reset()
+            env.step(np.arange(512) % 4)
+            assert env.kernel_name == "ns2d_fast2_sched"
+            return [env.sweeps.clone()]
+        return make, drive
+
+    def episode():
+        def make():
+            init = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))["fields"]
+            return V.VecRayleigh(512, DEV, "f32", init, L=2.56, H=1.28)
+
+        def drive(env):
+            acts = torch.as_tensor(np.random.default_rng(11).uniform(-1, 1, (8, 512, 10)), dtype=torch.float32, device=DEV)
+            env.reset()
+            env.set_stp((np.arange(512) * 7) % env.n_act)
+            sw = []
+            for k in range(24):
+                obs, rwd, done, trunc, _ = env.step(acts[k % 8])
+                sw.append(env.sweeps.sum(1).clone())
+                if int(done.sum().item()):
+                    env.reset_done()
+            assert env.kernel_name == "ns2d_fast_sched"
+            return sw
+        return make, drive
+
+    return {"jit75x50": jit_grid(1.5, 1.0), "jit110x64": jit_grid(2.2, 1.28), "jit60x120": jit_grid(1.2, 2.4),
+            "ra5e3_2sgts": ra_sgts(5.0e3, 2), "ra5e4_5sgts": ra_sgts(5.0e4, 5), "ra1e4_7sgts": ra_sgts(1.0e4, 7),
+            "mixing_full_b512": mixing_full(), "episode24_b512": episode()}
+
+
+@pytest.mark.parametrize("name", ["jit75x50", "jit110x64", "jit60x120", "ra5e3_2sgts", "ra5e4_5sgts", "ra1e4_7sgts",
+                                  "mixing_full_b512", "episode24_b512"])
+def test_float32_stop_rule_on_more_workloads(name):
+    """The float32 default (conv_plan 3: the extrapolating plan, guarded; speculative jump for rayleigh) on workloads the
+    first plan test does not reach: three on-demand grids (75x50, 110x64, 60x120), Ra = 5e3 / 5e4 / 1e4 with 2 / 5 / 7
+    bottom segments, a FULL 250-timestep mixing step at B=512 through the ticket scheduler, and the 24-step episode with
+    staggered auto-resets.  For each: (a) verify_conv evaluates every sweep and must not flag BCN_ST_PLAN, (b) sweep counts,
+    fields and observations equal, bit for bit, those of conv_plan 0 (every sweep evaluated, as rayleigh.py:448-454 does)
+    and of the run without the speculative jump, (c) no late stop is counted (bcn_get_counters), so nothing was repeated
+    under the proven plan either."""
+    make, drive = _plan_workloads()[name]
+
+    def run(**opts):
+        env = make()
+        for k, v in opts.items():
+            env.set_option(k, v)
+        sw = drive(env)
+        st = env.check_status()
+        out = (sw, env.get_state().clone(), env.obs.clone(), st.copy(), env.get_counters())
+        env.close()
+        return out
+
+    default = run()
+    assert int(default[3].max()) == 0
+    assert int(default[4][:, 2].sum()) == 0, "late stops on %s: %d" % (name, int(default[4][:, 2].sum()))
+    variants = {"verify": dict(verify_conv=1), "literal": dict(conv_plan=0), "nojump": dict(spec_start=0),
+                "plan2": dict(conv_plan=2), "proven": dict(conv_plan=1)}
+    for tag, opts in variants.items():
+        got = run(**opts)
+        assert int(got[3].max()) == 0, (name, tag, got[3].max())            # no BCN_ST_PLAN, no overflow
+        for a, b in zip(default[0], got[0]):
+            assert torch.equal(a, b), (name, tag, "sweep counts")
+        assert torch.equal(default[1], got[1]) and torch.equal(default[2], got[2]), (name, tag)
+
+
+@pytest.mark.parametrize("kind", ["rayleigh", "mixing"])
+def test_conv_plan_3_repeats_late_stops_under_the_proven_plan(kind):
+    """The guard itself.  "plan_overshoot" (a test hook) lengthens every skip of the extrapolating plan by 12 sweeps, so
+    its evaluations land behind the reference's stop sweep: plan 2 then stops late (larger sweep counts, late stops
+    counted), plan 3 must notice each of them, repeat the solve under the proven plan and return exactly the counts and
+    fields of conv_plan 0."""
+    def run(plan, over):
+        if kind == "rayleigh":
+            env, init, acts = _bench_workload(64, 1, "f32")
+            env.set_ndt_act(40)
+            env.reset()
+            a = acts[0]
+        else:
+            env = V.VecMixing(8, DEV, "f32")
+            env.set_ndt_act(40)
+            env.reset()
+            a = np.arange(8) % 4
+        env.set_option("conv_plan", plan)
+        env.set_option("plan_overshoot", over)
+        env.step(a)
+        env.check_status()
+        out = (env.sweeps.clone(), env.get_state().clone(), env.get_counters())
+        env.close()
+        return out
+    literal, plan2, plan3 = run(0, 0), run(2, 12), run(3, 12)
+    assert int(plan2[2][:, 2].sum()) > 0 and int((plan2[0] > literal[0]).sum()) > 0      # the hook does provoke late stops
+    assert int((plan2[0] < literal[0]).sum()) == 0                                       # late, never early
+    assert int(plan3[2][:, 2].sum()) > 0 and int(plan3[2][:, 3].sum()) >= int(plan3[2][:, 2].sum())
+    assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_speculative_first_evaluation_never_changes_a_result(dtype):
     """ns2d_fast_impl.h starts a Jacobi solve with spec_start/8 of the previous timestep's sweep count as double sweeps
@@ -1330,6 +1467,35 @@ def test_rayleigh_warmup_dump_load_roundtrip(tmp_path):
     s2.reset()
     assert np.allclose(s2.h[1:-1], s.h[1:-1], rtol=2e-5)
     s.close(), s2.close()
+
+
+def test_rayleigh_init_generation_on_the_gpu_matches_the_cpu_made_fixture():
+    """SURVEY 8f-1 (rayleigh/init.py:13-28): the developed 128x64 state the bench starts from, generated ON THE GPU --
+    VecRayleigh(n_sgts=1).develop(): seeded perturbed conduction state, n_warmup = 100 zero-action steps = 20 000
+    timesteps through the float64 register-resident kernel -- against tests/golden/rayleigh_128x64_init.npz, which
+    oracle/make_init.py produced with the float64 C oracle from the same start state.  The flow is a steady attractor
+    (Ra = 1e4), so rounding differences do not grow: fields and the whole Nusselt history agree to 1e-7 (the float64
+    kernel's own tolerance per step is 1e-9)."""
+    from oracle import make_init
+    z = np.load(os.path.join(GOLD, "rayleigh_128x64_init.npz"))
+    env = V.VecRayleigh(2, DEV, "f64", None, L=float(z["L"]), H=float(z["H"]), n_sgts=1)
+    _variant(env, 1)
+    _, T0 = make_init.start_state(float(z["L"]), float(z["H"]), int(z["seed"]))
+    assert np.array_equal(env.perturbed_conduction_state(int(z["seed"]))[3], T0)       # same start as the fixture's
+    fields = env.develop(int(z["n_steps"]), int(z["seed"]))
+    assert env.kernel_name == "ns2d_fast_step"
+    nu = -env.warmup_rwd.double().cpu().numpy()
+    assert nu.shape == (int(z["n_steps"]), 2) and np.array_equal(nu[:, 0], nu[:, 1])
+    assert maxdiff(nu[:, 0], z["nu"]) <= 1e-7, maxdiff(nu[:, 0], z["nu"])
+    for i, F in enumerate("uvpT"):
+        assert maxdiff(fields[i], z["fields"][i]) <= (5e-6 if F == "p" else 1e-7), (F, maxdiff(fields[i], z["fields"][i]))
+    assert (env.get_stp() == 0).all()
+    env.close()
+    # the generated state is what the constructor takes: reset() on it reproduces the fixture's reset observation
+    a = V.VecRayleigh(1, DEV, "f64", fields, L=float(z["L"]), H=float(z["H"]))
+    b = V.VecRayleigh(1, DEV, "f64", z["fields"], L=float(z["L"]), H=float(z["H"]))
+    assert maxdiff(a.reset()[0].cpu().numpy(), b.reset()[0].cpu().numpy()) <= 1e-7
+    a.close(), b.close()
 
 
 def test_shkadov_separable_mirror():
