@@ -45,7 +45,7 @@ __attribute__((visibility("default"))) size_t bcn_jit_scratch_elems(void) {
 
 __attribute__((visibility("default"))) size_t bcn_jit_lds_bytes(void) {
 #if BCN_JIT_ROWS == 1
-  return FastGeom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::lds_elems() * sizeof(BCN_JIT_REAL);
+  return FastGeom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::lds_bytes<BCN_JIT_REAL>();
 #else
   return Fast2Geom<BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_R, BCN_JIT_GF>::lds_elems() * sizeof(BCN_JIT_REAL);
 #endif

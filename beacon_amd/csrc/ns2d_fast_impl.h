@@ -81,8 +81,18 @@ struct FastGeom {
   static constexpr int BACK = (NY + 3 * PD + 2) * SY;   // the transport wave prefetches two blocks of PD diagonals ahead
   static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
   static constexpr int MISCA = (MISC + 15) / 16 * 16;
-  static constexpr size_t lds_elems() {
+  static constexpr size_t base_elems() {
     return GF == 1 ? (size_t)MISCA : GF == 2 ? (size_t)MISCA + 2 * (size_t)SZ : (size_t)FRONT + 3 * (size_t)SZ + BACK;
+  }
+  // While wave 0 walks the ordered part of the transport step, the other waves compute the next timestep's predictor -- and,
+  // where LDS has room for it, wave 0's strip as well: p of strip 0 in, u*, and the v* increment without buoyancy out,
+  // [3][R][64] elements behind everything else (fast_body)
+  static constexpr size_t SCR = 3 * (size_t)R * 64;
+  template <typename real> static constexpr bool offload() {
+    return NW >= 3 && (base_elems() + SCR) * sizeof(real) <= 160 * 1024;
+  }
+  template <typename real> static constexpr size_t lds_bytes() {
+    return (base_elems() + (offload<real>() ? SCR : 0)) * sizeof(real);
   }
   static constexpr size_t scratch_elems() {
     return GF == 1 ? (size_t)FRONTG + 3 * (size_t)SZ + BACK : GF == 2 ? (size_t)FRONTG + SZ + BACK : 0;
@@ -117,20 +127,29 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
   for (int i = 1 + lane; i <= NX; i += 64) Tl[i * SY + 1] += (c0y + c1y * Ul[i * SY + 1 + G::SZ]) * Tl[i * SY];
   float tp = Tl[0 * SY + j];                        // west ghost
   float aA[PD], uA[PD], vA[PD], aB[PD], uB[PD], vB[PD];
-#define BCN_LOAD(RA, RU, RV, T0)                                                              \
+  // Tc / Uc: this lane's element of the first diagonal of the current trip (T and A share an array, V sits SZ behind U);
+  // OFF: diagonal offset inside the trip (compile time: every LDS access of a trip is base register + immediate)
+  // (LDS pointers, 32 bit: as generic pointers of this out-of-line function every access of the rolled loops paid a
+  // 64-bit add and a null-checked address-space conversion)
+  typedef __attribute__((address_space(3))) float lds_f;
+  lds_f* Tc = (lds_f*)Tb;
+  const lds_f* Uc = (const lds_f*)(Ul + cb);
+  lds_f* const dummyL = (lds_f*)dummy;
+#define BCN_LOAD(RA, RU, RV, OFF)                                                             \
   {                                                                                           \
-    const float* const Tq = Tb + (T0) * SY;                                                   \
-    const float* const Uq = Ul + cb + (T0) * SY;                                              \
-    const float* const Vq = Uq + G::SZ;                                                       \
+    const lds_f* const Tq = Tc + (OFF) * SY;                                                  \
+    const lds_f* const Uq = Uc + (OFF) * SY;                                                  \
+    const lds_f* const Vq = Uq + G::SZ;                                                       \
     RA[0] = Tq[0]; RA[1] = Tq[SY]; RA[2] = Tq[2 * SY]; RA[3] = Tq[3 * SY];                    \
     RU[0] = Uq[0]; RU[1] = Uq[SY]; RU[2] = Uq[2 * SY]; RU[3] = Uq[3 * SY];                    \
     RV[0] = Vq[0]; RV[1] = Vq[SY]; RV[2] = Vq[2 * SY]; RV[3] = Vq[3 * SY];                    \
   }
-  // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
-#define BCN_BLOCK(RA, RU, RV, NA, NU, NV, T0, MASK)                                           \
+  // MASK 0: every lane inside, or running on behind the domain; 1: lanes <= t; 2: lanes > t - NX; 3: both tests; 4: as 1
+  // for NY == 64, by value
+#define BCN_BLOCK(RA, RU, RV, NA, NU, NV, OFF, MASK)                                          \
   {                                                                                           \
-    BCN_LOAD(NA, NU, NV, (T0) + PD)                                                           \
-    float* const Tq = Tb + (T0) * SY;                                                         \
+    BCN_LOAD(NA, NU, NV, (OFF) + PD)                                                          \
+    lds_f* const Tq = Tc + (OFF) * SY;                                                        \
     float tq[PD];                                                                             \
     bool okq[PD];                                                                             \
     /* the coefficients of two diagonals per packed fma: a lone wave issues a v_pk_fma_f32 in the time of a v_fma_f32 */ \
@@ -141,35 +160,46 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
       asp[q] = c0y + c1y * rv;                                                                \
     }                                                                                         \
     _Pragma("unroll") for (int q = 0; q < PD; q++) {                                          \
-      const int t = (T0) + q;                                                                 \
+      const int t = t0 + (OFF) + q;                                                           \
       const float aw = awp[q / 2][q & 1], as = asp[q / 2][q & 1];                             \
       float t1 = RA[q] + aw * tp;                                                             \
       asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
                    : "+v"(t1) : "v"(tp), "v"(as));                                            \
-      tq[q] = t1;                                                                             \
-      okq[q] = (MASK == 0) || (active && (MASK != 2 ? (lane <= t) : true) &&                  \
-                               (MASK != 1 ? (lane > t - NX && t < NSTEP) : true));            \
+      okq[q] = (MASK == 0) || (MASK == 4 ? (lane <= t) : (active && (MASK != 2 ? (lane <= t) : true) && \
+                               (MASK != 1 ? (lane > t - NX && t < NSTEP) : true)));           \
       tp = okq[q] ? t1 : tp;                                                                  \
+      /* MASK 4 (every row active, lanes <= t): a lane in front of the domain stores the value it loaded back (its cell \
+         lies in column 0 or in the array in front of T, which nothing writes during the sweep): the stores keep their \
+         immediate offsets and pair up, instead of a selected address per step */            \
+      tq[q] = (MASK == 4 && !okq[q]) ? RA[q] : t1;                                            \
     }                                                                                         \
-    if (MASK == 0) {                                                                          \
+    if (MASK == 0 || MASK == 4) {                                                             \
       Tq[0] = tq[0]; Tq[SY] = tq[1]; Tq[2 * SY] = tq[2]; Tq[3 * SY] = tq[3];                  \
     } else {                                                                                  \
-      _Pragma("unroll") for (int q = 0; q < PD; q++) { float* dst = okq[q] ? Tq + q * SY : dummy; *dst = tq[q]; } \
+      _Pragma("unroll") for (int q = 0; q < PD; q++) { lds_f* dst = okq[q] ? Tq + q * SY : dummyL; *dst = tq[q]; } \
     }                                                                                         \
   }
+  // The loops stay rolled (a trip = two blocks of four diagonals, two register sets): unrolled, the sweep is 18 KB of
+  // straight-line code that the lone wave streams through the instruction cache once per timestep -- next to the other
+  // waves' predictor code (fast_body) that doubled its time.
 #define BCN_CHAIN2(T0, T1, MASK)                                                              \
-  for (int t0 = (T0); t0 < (T1); t0 += 2 * PD) {                                              \
-    BCN_BLOCK(aA, uA, vA, aB, uB, vB, t0, MASK)                                               \
-    BCN_BLOCK(aB, uB, vB, aA, uA, vA, t0 + PD, MASK)                                          \
+  _Pragma("nounroll") for (int t0 = (T0); t0 < (T1); t0 += 2 * PD) {                          \
+    BCN_BLOCK(aA, uA, vA, aB, uB, vB, 0, MASK)                                                \
+    BCN_BLOCK(aB, uB, vB, aA, uA, vA, PD, MASK)                                               \
+    Tc += 2 * PD * SY;                                                                        \
+    Uc += 2 * PD * SY;                                                                        \
   }
   BCN_LOAD(aA, uA, vA, 0)
   // lanes 0..NY-1 are all inside the domain for t in [NY-1, NX); phase bounds are multiples of 2 PD
   constexpr int P2 = 2 * PD;
   constexpr int TA2 = ((NY - 1 + P2 - 1) / P2) * P2, TB2 = (NX / P2) * P2, TE2 = ((NSTEP + P2 - 1) / P2) * P2;
   if constexpr (TA2 <= TB2 && NY == 64) {
-    BCN_CHAIN2(0, TA2, 1)
-    BCN_CHAIN2(TA2, TB2, 0)
-    BCN_CHAIN2(TB2, TE2, 2)
+    // Behind the domain (i > NX) a lane simply runs on: its garbage lands in the pad behind T -- and, in its first step
+    // out, in the east ghost column, which is saved here and put back (no masks at all in the last third of the sweep)
+    const float east = Tl[(NX + 1) * SY + j];
+    BCN_CHAIN2(0, TA2, 4)
+    BCN_CHAIN2(TA2, TE2, 0)
+    Tl[(NX + 1) * SY + j] = east;
   } else {
     BCN_CHAIN2(0, TE2, 3)
   }
@@ -199,7 +229,7 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
   real tp = Tl[0 * SY + j];                        // west ghost
   // MASK 0: every lane inside (steady state); 1: lanes <= t; 2: lanes > t - NX; 3: both tests
 #define BCN_CHAIN(T0, T1, MASK)                                                             \
-  for (int t0 = (T0); t0 < (T1); t0 += PD) {                                                \
+  _Pragma("nounroll") for (int t0 = (T0); t0 < (T1); t0 += PD) {                            \
     _Pragma("unroll") for (int q = 0; q < PD; q++) {                                        \
       const int t = t0 + q;                                                                 \
       const real s = from_below(rg[q], tp);                                                 \
@@ -318,7 +348,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   int xb = 0;
 #ifdef BCN_STAMP
   const unsigned long long kt0 = __builtin_amdgcn_s_memtime(), kr0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long seg[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl = kt0;
 #define BCN_PH(x) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); seg[x] += t__ - tl; tl = t__; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -338,12 +368,47 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #else
   if (tid == 0) prev_sweeps[0] = 0;
 #endif
-  // prev_sweeps[1]: this timestep's solve runs under the proven plan (a repeat, conv_plan 3); [2]: solves whose stop sweep the
-  // extrapolating plan could not verify ("late stops"); [3]: timesteps repeated (speculative jump too far, or conv_plan 3)
+  // prev_sweeps[1]: this solve runs under the proven plan (a repeat, conv_plan 3); [2]: solves whose stop sweep the
+  // extrapolating plan could not verify ("late stops"); [3]: solves repeated (speculative jump too far, or conv_plan 3)
   if (tid == 0) { prev_sweeps[1] = 0; prev_sweeps[2] = 0; prev_sweeps[3] = 0; }
-  for (int it = it_begin; it < it_end && status == 0; it++) {
-    if (GF) asm volatile("" : "+v"(j));
-    // ---- boundary conditions on the LDS fields (rayleigh.py:180-202) ------------------------
+
+  // A timestep is software-pipelined against its successor: the ordered part of the scalar transport (rayleigh.py:468-487)
+  // is a chain of nx+ny-1 dependent steps that ONE wave walks (transport_chain*), and nothing in the next timestep's
+  // predictor depends on the new T except the buoyancy term of v*, which is linear in T[i,j] (rayleigh.py:370-407).  So
+  // while wave 0 walks the chain of timestep n, the other waves apply the velocity boundary conditions of timestep n+1
+  // (in the phase before) and compute its whole predictor without buoyancy: u*, and X = diff - conv - dp/dy of v* (kept
+  // with the old v: v* = v + dt (X + T) is finished behind the chain's barrier -- the same operations in the same order
+  // as the unsplit form).  Where LDS has room (OFFLOAD), the helper waves also compute strip 0 (from p of strip 0 that
+  // wave 0 left in LDS) and wave 0 only loads its u*, X; otherwise wave 0 computes its own strip behind the chain.
+  constexpr bool OFFLOAD = G::template offload<real>();
+  real* const P0 = exch + G::base_elems();   // [R][64] p of strip 0; then u* [R][64] and X [R][64] of strip 0
+  real* const US0 = P0 + R0 * 64;
+  real* const VX0 = US0 + R0 * 64;
+  // one cell of the predictor (rayleigh.py:370-407) without the buoyancy term: u* (complete) and X of v*
+  auto pred = [&](const int i, real uc, real uE_, real uW_, real uN_, real uS_, real uSE_, real vc, real vE_, real vW_, real vN_,
+                  real vS_, real vNW_, real pc, real pW, real pS, real& us_out, real& vx_out) {
+    {
+      real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+      real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
+      real vN2 = real(0.5) * (vN_ + vNW_), vS2 = real(0.5) * (vc + vW_);
+      real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
+      real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
+      real pres = (pc - pW) * rdx;
+      us_out = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
+    }
+    {
+      real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+      real uE = real(0.5) * (uE_ + uSE_), uW = real(0.5) * (uc + uS_);
+      real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
+      real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
+      real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
+      real pres = (pc - pS) * rdy;
+      vx_out = diff - conv - pres;
+    }
+  };
+  // velocity boundary conditions (rayleigh.py:180-202, the u, v part): they read interior values the corrector has
+  // finished and write ghost cells / wall faces that neither the corrector nor the transport step reads
+  auto bc_uv = [&]() {
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
       Ul[1 * SY + jj] = 0;
       Ul[(NX + 1) * SY + jj] = 0;
@@ -351,8 +416,6 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         Vl[0 * SY + jj] = -Vl[1 * SY + jj];
         Vl[(NX + 1) * SY + jj] = -Vl[NX * SY + jj];
       }
-      Tl[0 * SY + jj] = Tl[1 * SY + jj];
-      Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
     }
     for (int ii = 1 + tid; ii <= NX + 1; ii += NT) {
       const bool wall = (ii == 1) || (ii == NX + 1);
@@ -363,68 +426,151 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       if (ii <= NX) {
         Vl[ii * SY + NY + 1] = 0;
         Vl[ii * SY + 1] = 0;
-        Tl[ii * SY + NY + 1] = 2 * A.Tc - Tl[ii * SY + NY];
-        const int k = (ii - 1) / A.nx_sgts;
-        if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
       }
     }
+  };
+  // what the next predictor needs from the other strips / from wave 0: the strip's last p column, p of strip 0
+  auto publish_p = [&]() {
     ex(xb, w, 1)[lane] = p[R - 1];
-    __syncthreads();
-    if (GF) asm volatile("" : "+v"(j));
-    BCN_PH(0)
+    if (OFFLOAD && w == 0) {
+#pragma unroll
+      for (int k = 0; k < R; k++) P0[k * 64 + lane] = p[k];
+    }
+  };
 
-    // ---- predictor (rayleigh.py:370-407) -> u*, v* in registers -----------------------------
-    real us[R], vs[R];
-    {
-      const real pWh = (w > 0) ? ex(xb, w - 1, 1)[lane] : real(0);
-      xb ^= 1;
-      // float64 (GF) and wide strips: in chunks of CH columns, so that the seven neighbour arrays fit the register file
-      constexpr bool WIDE = (R > 16) || (R > 12 && NW > 8);   // more live values than the wave's register budget
-      constexpr int CH = GF ? 4 : (!WIDE ? R : (R % 4 == 0 ? 4 : 5));   // the last chunk may be shorter (kk < R below)
+  // prologue of this unit: boundary conditions and p exchange of its first timestep
+  bc_uv();
+  publish_p();
+  __syncthreads();
+
+  real us[R], vs[R];
+  for (int it = it_begin;; it++) {
+    asm volatile("" : "+v"(j));   // keep hipcc from hoisting (and spilling) a whole timestep's LDS addresses out of the loop
+    const bool have_chain = it > it_begin;                     // the ordered transport part of timestep it - 1 is pending
+    const bool have_pred = it < it_end && status == 0;         // timestep it runs in this unit
+    // ======== ordered part of the transport step (wave 0)  ||  predictor without buoyancy of the next timestep ========
+    real vx[R];   // X of v* of this thread's cells
+    // own strip: every wave in the unit's first timestep; behind that the helper waves (wave 0: below)
+    const bool pred_own = have_pred && (w != 0 || !have_chain);
+    if (w == 0 && have_chain) {
+#ifndef BCN_CHAIN_PRIO
+#define BCN_CHAIN_PRIO 3
+#endif
+      // the chain is the critical path of this region: its wave outranks the predictor of the wave it shares a SIMD with
+      __builtin_amdgcn_s_setprio(BCN_CHAIN_PRIO);
+      if constexpr (std::is_same<real, float>::value && GF == 0)
+        transport_chain_f32<NX, NY, R0>(Tl, Ul, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2,
+                                        real(0.5) * dt * rdy);
+      else
+        transport_chain<real, NX, NY, R0, GF>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+                                              dt * A.ksc * rdy2, real(0.5) * dt * rdy);
+      __builtin_amdgcn_s_setprio(0);
+      BCN_PH(6)
+    }
+#define BCN_OWN_PRED                                                                                            \
+    {                                                                                                           \
+      const real pWh = (w > 0) ? ex(xb, w - 1, 1)[lane] : real(0);                                              \
+      /* float64 (GF) and wide strips: in chunks of CH columns, so that the neighbour arrays fit the register file */ \
+      constexpr bool WIDE = (R > 16) || (R > 12 && NW > 8);   /* more live values than the wave's register budget */ \
+      constexpr int CH = GF ? 4 : (!WIDE ? R : (R % 4 == 0 ? 4 : 5));   /* the last chunk may be shorter (kk < R below) */ \
+      _Pragma("unroll") for (int c0 = 0; c0 < R; c0 += CH) {                                                    \
+        if (CH != R) __builtin_amdgcn_sched_barrier(0);   /* finish one chunk before loading the next */        \
+        real ur[CH + 2], uS[CH + 1], uN[CH], vr[CH + 2], vN[CH + 1], vS[CH];                                    \
+        const int ic = i0 + c0;                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < CH + 2; k++) { ur[k] = Ul[(ic - 1 + k) * SY + j]; vr[k] = Vl[(ic - 1 + k) * SY + j]; } \
+        _Pragma("unroll") for (int k = 0; k < CH + 1; k++) { uS[k] = Ul[(ic + k) * SY + j - 1]; vN[k] = Vl[(ic - 1 + k) * SY + j + 1]; } \
+        _Pragma("unroll") for (int k = 0; k < CH; k++) { uN[k] = Ul[(ic + k) * SY + j + 1]; vS[k] = Vl[(ic + k) * SY + j - 1]; } \
+        _Pragma("unroll") for (int k = 0; k < CH; k++) {                                                        \
+          const int kk = c0 + k;                                                                                \
+          if (kk >= R) continue;   /* remainder chunk (resolved at compile time) */                             \
+          const real pc = p[kk < R ? kk : 0];                                                                   \
+          const real pW = (kk > 0) ? p[kk > 0 && kk <= R ? kk - 1 : 0] : pWh;                                   \
+          const real pS = from_below(pc, pc);                                                                   \
+          pred(ic + k, ur[k + 1], ur[k + 2], ur[k], uN[k], uS[k], uS[k + 1], vr[k + 1], vr[k + 2], vr[k], vN[k + 1], vS[k], \
+               vN[k], pc, pW, pS, us[kk < R ? kk : 0], vx[kk < R ? kk : 0]);                                    \
+        }                                                                                                       \
+      }                                                                                                         \
+    }
+#ifdef BCN_DBG_NOHELP   // timing experiment (same results): nothing runs beside the chain, every wave computes its own strip behind it
+    __syncthreads();
+    if (have_pred) BCN_OWN_PRED
+    if constexpr (false) {
+#else
+    if (pred_own) BCN_OWN_PRED
+    if constexpr (OFFLOAD) {
+#endif
+      // strip 0 for wave 0, in chunks of four columns dealt to the helper waves (in an 8-wave workgroup wave 4 shares its
+      // SIMD with wave 0: it comes last)
+      if (have_pred && have_chain && w != 0) {
+        constexpr int CH0 = 4, NCH0 = (R0 + CH0 - 1) / CH0;
+        const int rank = (NW == 8) ? (w < 4 ? w - 1 : (w == 4 ? 6 : w - 2)) : w - 1;
 #pragma unroll
-      for (int c0 = 0; c0 < R; c0 += CH) {
-        if (CH != R) __builtin_amdgcn_sched_barrier(0);   // finish one chunk before loading the next
-        real ur[CH + 2], uS[CH + 1], uN[CH], vr[CH + 2], vN[CH + 1], vS[CH], Tc[CH];
-        const int ic = i0 + c0;
+        for (int c = 0; c < NCH0; c++) {
+          if (c % (NW - 1) != rank) continue;
+          __builtin_amdgcn_sched_barrier(0);
+          real ur[CH0 + 2], uS[CH0 + 1], uN[CH0], vr[CH0 + 2], vN[CH0 + 1], vS[CH0], pp[CH0 + 1];
+          const int ic = 1 + c * CH0;
 #pragma unroll
-        for (int k = 0; k < CH + 2; k++) { ur[k] = Ul[(ic - 1 + k) * SY + j]; vr[k] = Vl[(ic - 1 + k) * SY + j]; }
+          for (int k = 0; k < CH0 + 2; k++) { ur[k] = Ul[(ic - 1 + k) * SY + j]; vr[k] = Vl[(ic - 1 + k) * SY + j]; }
 #pragma unroll
-        for (int k = 0; k < CH + 1; k++) { uS[k] = Ul[(ic + k) * SY + j - 1]; vN[k] = Vl[(ic - 1 + k) * SY + j + 1]; }
+          for (int k = 0; k < CH0 + 1; k++) { uS[k] = Ul[(ic + k) * SY + j - 1]; vN[k] = Vl[(ic - 1 + k) * SY + j + 1]; }
 #pragma unroll
-        for (int k = 0; k < CH; k++) { uN[k] = Ul[(ic + k) * SY + j + 1]; vS[k] = Vl[(ic + k) * SY + j - 1]; Tc[k] = Tl[(ic + k) * SY + j]; }
+          for (int k = 0; k < CH0; k++) { uN[k] = Ul[(ic + k) * SY + j + 1]; vS[k] = Vl[(ic + k) * SY + j - 1]; }
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const int i = ic + k, kk = c0 + k;
-          if (kk >= R) continue;   // remainder chunk (resolved at compile time)
-          const real uc = ur[k + 1], uE_ = ur[k + 2], uW_ = ur[k], uN_ = uN[k], uS_ = uS[k];
-          const real vc = vr[k + 1], vE_ = vr[k + 2], vW_ = vr[k], vN_ = vN[k + 1], vS_ = vS[k];
-          const real pc = p[kk < R ? kk : 0];
-          const real pW = (kk > 0) ? p[kk > 0 && kk <= R ? kk - 1 : 0] : pWh;
-          const real pS = from_below(pc, pc);
-          {
-            real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
-            real uN2 = real(0.5) * (uN_ + uc), uS2 = real(0.5) * (uc + uS_);
-            real vN2 = real(0.5) * (vN_ + vN[k]), vS2 = real(0.5) * (vc + vW_);
-            real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
-            real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
-            real pres = (pc - pW) * rdx;
-            us[kk] = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
+          for (int k = 0; k <= CH0; k++) {
+            const int kk = c * CH0 + k - 1;          // p column of strip 0 (-1: the wall, no pressure gradient there)
+            pp[k] = (kk >= 0 && kk < R0) ? P0[(kk >= 0 && kk < R0 ? kk : 0) * 64 + lane] : real(0);
           }
-          {
-            real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
-            real uE = real(0.5) * (uE_ + uS[k + 1]), uW = real(0.5) * (uc + uS_);
-            real vN2 = real(0.5) * (vN_ + vc), vS2 = real(0.5) * (vc + vS_);
-            real conv = (uE * vE - uW * vW) * rdx + (vN2 * vN2 - vS2 * vS2) * rdy;
-            real diff = ((vE_ - 2 * vc + vW_) * rdx2 + (vN_ - 2 * vc + vS_) * rdy2) * A.kmom;
-            real pres = (pc - pS) * rdy;
-            const real buoy = (KIND == 0) ? Tc[k] : real(0);
-            vs[kk] = (j >= 2 && active) ? vc + dt * (diff - conv - pres + buoy) : real(0);
+#pragma unroll
+          for (int k = 0; k < CH0; k++) {
+            const int kk = c * CH0 + k;
+            if (kk >= R0) continue;
+            const real pc = pp[k + 1];
+            const real pS = from_below(pc, pc);
+            real uo, xo;
+            pred(ic + k, ur[k + 1], ur[k + 2], ur[k], uN[k], uS[k], uS[k + 1], vr[k + 1], vr[k + 2], vr[k], vN[k + 1], vS[k], vN[k],
+                 pc, pp[k], pS, uo, xo);
+            US0[(kk < R0 ? kk : 0) * 64 + lane] = uo;
+            VX0[(kk < R0 ? kk : 0) * 64 + lane] = xo;
           }
         }
       }
     }
-    ex(xb, w, 0)[lane] = us[0];
+    if (w != 0) { BCN_PH(6) }
+    if (have_pred) xb ^= 1;                          // (the p exchange buffer has been read)
+    if (have_pred && w != 0) ex(xb, w, 0)[lane] = us[0];   // for the rhs of the strip to the west (nobody needs wave 0's)
     __syncthreads();
+    BCN_PH(5)
+    if (!have_pred) break;
+    asm volatile("" : "+v"(j));   // keep hipcc from hoisting (and spilling) a whole timestep's LDS addresses out of the loop
+#ifndef BCN_DBG_NOHELP
+    if (w == 0 && have_chain) {
+      if constexpr (OFFLOAD) {
+#pragma unroll
+        for (int k = 0; k < R; k++) { us[k] = US0[k * 64 + lane]; vx[k] = VX0[k * 64 + lane]; }
+      } else {
+        BCN_OWN_PRED
+      }
+    }
+#endif
+#undef BCN_OWN_PRED
+    // ---- boundary conditions of T (rayleigh.py:180-202, the T part) on the transported field --------------
+    for (int jj = 1 + tid; jj <= NY; jj += NT) {
+      Tl[0 * SY + jj] = Tl[1 * SY + jj];
+      Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
+    }
+    for (int ii = 1 + tid; ii <= NX; ii += NT) {
+      Tl[ii * SY + NY + 1] = 2 * A.Tc - Tl[ii * SY + NY];
+      const int k = (ii - 1) / A.nx_sgts;
+      if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
+    }
+    // ---- buoyancy: v* = v + dt (X + T) (rayleigh.py:405) ----------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+      const real buoy = (KIND == 0) ? Tl[(i0 + k) * SY + j] : real(0);
+      vs[k] = (j >= 2 && active) ? Vl[(i0 + k) * SY + j] + dt * (vx[k] + buoy) : real(0);   // (the old v: re-read, not kept)
+    }
+    BCN_PH(0)
 
     // ---- Poisson rhs (rayleigh.py:424-426) ---------------------------------------------------
     real nb[R];   // minus the scaled rhs
@@ -488,15 +634,28 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     };
     real hW = 0, hE = 0;            // halos of the array the last sweep read
     // columns -1, -2 / R, R+1 of the array the last sweep wrote (LDS reads issued behind its barrier)
-    real hW1r = 0, hW2r = 0, hE1r = 0, hE2r = 0;
-    int itp = 0;
+    real hW1r, hW2r, hE1r, hE2r;
+    int itp;
+    real phA[R], phB[R];
+    bool finalB;
+    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+    constexpr int JMAX = 256;
+#ifdef BCN_DBG_NCHK
+    int nchk = 0;
+#define BCN_NCHK_INC nchk++;
+#else
+#define BCN_NCHK_INC
+#endif
 #ifdef BCN_STAMP
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
-    real phA[R], phB[R];
+    for (;;) {   // the solve of this timestep: once -- again when a speculative jump went too far or, under conv_plan 3, when
+                 // the extrapolating plan did not foresee the stop (below); u*, v* and the rhs are untouched by the sweeps
+    hW1r = 0; hW2r = 0; hE1r = 0; hE2r = 0;
+    itp = 0;
 #pragma unroll
     for (int k = 0; k < R; k++) phA[k] = 0;
-    bool finalB = false;
+    finalB = false;
     int k_prev = -1;                // index of the planned evaluation before the last one, log2 of its two norms
     float l2u_prev = 0, l2w_prev = 0;
     int skip_left = 0;              // verify_conv: sweeps the plan would still skip; -2 / -1: speculative jump pending / failed
@@ -504,17 +663,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     // the ghost copies), so behind the evaluations of sweeps 1 and 2 the next one may sit at sweep m: if it does not pass,
     // no sweep in between did.  m = spec_start/8 of the previous timestep's count (consecutive timesteps of the bench
     // workload differ by < 30 % in 611 000 solves).  If the evaluation at m DOES pass the test (or, under the proven plan,
-    // its unweighted norm is not above the threshold), the whole timestep is repeated without the jump -- the result never
+    // its unweighted norm is not above the threshold), the solve is repeated without the jump -- the result never
     // depends on the guess.  The bookkeeping lives in `skip_left` (unused without verify_conv) and in LDS: every scalar
     // register more in this loop costs hipcc dozens of SGPR spills (v_readlane) around the sweeps.
-#ifdef BCN_DBG_NCHK
-    int nchk = 0;
-#define BCN_NCHK_INC nchk++;
-#else
-#define BCN_NCHK_INC
-#endif
-    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
-    constexpr int JMAX = 256;
     // the evaluation plan of THIS solve: conv_plan 3 is plan 2 whose unverified stops are repeated under plan 1
     const int plan = (A.conv_plan == 3) ? (__builtin_amdgcn_readfirstlane((int)prev_sweeps[1]) != 0 ? 1 : 2) : A.conv_plan;
     // all cells of one sweep; the two strip-edge cells come last (their halos were requested behind the previous
@@ -670,18 +821,18 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       // Guard of the extrapolating plan (conv_plan 2, 3).  A stop at sweep s is the reference's stop sweep when sweep s - 1
       // was evaluated (and failed); when the passing evaluation directly follows SKIPPED sweeps the plan's own estimate was
       // wrong -- the decay accelerated -- and an earlier sweep may have passed as well: a "late stop", counted per replica
-      // (bcn_get_counters).  conv_plan 3 repeats such a timestep under the proven plan 1, as a jump that went too far
-      // (skip_left == -1) repeats it without the guess: BC, predictor and rhs recompute the same values from the
-      // unchanged fields.
+      // (bcn_get_counters).  conv_plan 3 repeats such a solve under the proven plan 1, as a jump that went too far
+      // (skip_left == -1) repeats it without the guess.
       const bool toofar = SPEC && skip_left == -1;
       const bool late = plan >= 2 && !toofar && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
       if (late && tid == 0) prev_sweeps[2] += 1;
-      if (toofar || (late && A.conv_plan == 3)) {
-        if (tid == 0) { prev_sweeps[0] = 0; prev_sweeps[1] = toofar ? real(0) : real(1); prev_sweeps[3] += 1; }
-        it--;
-        continue;
+      if (!(toofar || (late && A.conv_plan == 3))) {
+        if (tid == 0) { prev_sweeps[0] = SPEC ? (real)itp : real(0); prev_sweeps[1] = 0; }
+        break;
       }
-      if (tid == 0) { prev_sweeps[0] = SPEC ? (real)itp : real(0); prev_sweeps[1] = 0; }
+      if (tid == 0) { prev_sweeps[0] = 0; prev_sweeps[1] = toofar ? real(0) : real(1); prev_sweeps[3] += 1; }
+      __syncthreads();   // the words above are read at the head of the repeated solve
+    }
     }
     if (finalB) {
 #pragma unroll
@@ -701,7 +852,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #endif
 
     cyc_j += __builtin_amdgcn_s_memtime() - cyc_j0;
-    if (GF) asm volatile("" : "+v"(j));
+    asm volatile("" : "+v"(j));   // keep hipcc from hoisting (and spilling) a whole timestep's LDS addresses out of the loop
     BCN_PH(2)
     // ---- p += phi (rayleigh.py:219), corrector (rayleigh.py:460-464) -> LDS u, v --------------
 #pragma unroll
@@ -718,9 +869,10 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     }
     __syncthreads();
 
-    if (GF) asm volatile("" : "+v"(j));
+    asm volatile("" : "+v"(j));   // keep hipcc from hoisting (and spilling) a whole timestep's LDS addresses out of the loop
     BCN_PH(3)
-    // ---- transport, explicit part of every cell (rayleigh.py:468-487) ------------------------
+    // ---- transport, explicit part of every cell (rayleigh.py:468-487); next to it, with the corrected u, v: the velocity
+    //      boundary conditions and the p exchange of the NEXT timestep of this unit ------------------------------
     {
       real Ac[R];
 #pragma unroll
@@ -733,6 +885,10 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
                           (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
         Ac[k] = T0 + dt * expl;
       }
+      if (it + 1 < it_end && status == 0) {
+        bc_uv();
+        publish_p();
+      }
       __syncthreads();   // every read of the old T is done
       if (active) {
 #pragma unroll
@@ -740,21 +896,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       }
     }
     __syncthreads();
-
-    if (GF) asm volatile("" : "+v"(j));
     BCN_PH(4)
-    // ---- transport, ordered part: one wave walks the anti-diagonals --------------------------
-    if (w == 0) {
-      if constexpr (std::is_same<real, float>::value && GF == 0)
-        transport_chain_f32<NX, NY, R0>(Tl, Ul, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2,
-                                        real(0.5) * dt * rdy);
-      else
-        transport_chain<real, NX, NY, R0, GF>(Tl, Ul, Vl, red + 16, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
-                                              dt * A.ksc * rdy2, real(0.5) * dt * rdy);
-    }
-    __syncthreads();
-    BCN_PH(5)
   }
+#undef BCN_NCHK_INC
 
   // ---- store: LDS [i][j] -> HBM [j][i]; p and its ghosts -------------------------------------
   for (int c = tid; c < SX * SY; c += NT) {
@@ -781,8 +925,11 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   {
     const unsigned long long kt1 = __builtin_amdgcn_s_memtime(), kr1 = __builtin_amdgcn_s_memrealtime();
     status = (int)((kt1 - kt0) * 100ull / (kr1 - kr0 + 1));
-    if (tid == 0 && A.actions_norm)
-      for (int q = 0; q < 6; q++) A.actions_norm[(size_t)b * A.n_sgts + q] = (real)seg[q] / (real)(it_end - it_begin);
+#ifndef BCN_STAMP_WAVE
+#define BCN_STAMP_WAVE 0     // the wave whose phase times are reported
+#endif
+    if (tid == 64 * BCN_STAMP_WAVE && A.actions_norm)
+      for (int q = 0; q < 7; q++) A.actions_norm[(size_t)b * A.n_sgts + q] = (real)seg[q] / (real)(it_end - it_begin);
 
   }
 #endif
@@ -864,7 +1011,7 @@ template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
 int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   using G = FastGeom<NX, NY, R, GF>;
   if (GF && (!a.fscr || a.fscr_stride < G::scratch_elems())) { bcn_set_error("fast path: field scratch missing"); return BCN_ERR_UNSUPPORTED; }
-  const size_t lds = G::lds_elems() * sizeof(real);
+  const size_t lds = G::template lds_bytes<real>();
   auto k = ns2d_fast_step<real, NX, NY, R, KIND, EQ, GF>;
   static unsigned long long attr_set = 0;
   if (ns2d_first_on_device(attr_set)) {

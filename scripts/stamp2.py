@@ -1,5 +1,6 @@
 # diagnostic: build variants of the fast kernel (-D flags) and report cycles/sweep + step time
 import os, sys, time, numpy as np, torch
+os.environ.setdefault("BCN_SCHED", "0")
 sys.path.insert(0, os.getcwd())
 from beacon_amd import build
 extra = sys.argv[1:]
@@ -18,4 +19,4 @@ for k in range(3):
     sw = env.sweeps.cpu().numpy(); itp, cps = sw & 0xffff, sw >> 16
 print(extra, "step ms %.2f" % ((t1 - t0) * 1e3), "sweeps/dt %.1f" % itp.mean(), "cycles/sweep %.0f" % ((cps * itp).sum() / itp.sum()),
       "clock MHz %.0f" % env.status.cpu().numpy().mean(),
-      "cycles/timestep BC/pred+rhs/jacobi/corr/transp-expl/chain", env.actions_norm.cpu().numpy()[:, :6].mean(0).round(0))
+      "cycles/timestep bcT+buoy/rhs/jacobi/corr/transp-expl+bcuv/(chain||pred)+barrier/chain", env.actions_norm.cpu().numpy()[:, :7].mean(0).round(0))

@@ -618,21 +618,28 @@ def _plan_workloads():
             return sw
         return make, drive
 
+    # (Ra = 5e3 is not a valid configuration of the REFERENCE: at dt = 0.01 its explicit scalar transport has a diffusion
+    # number of 0.84 there and the float64 reference itself blows up to NaN around timestep 60 -- sweep counts 1195,
+    # 15950, 43272, then 1 for ever -- so the low-Ra case is Ra = 2e4)
     return {"jit75x50": jit_grid(1.5, 1.0), "jit110x64": jit_grid(2.2, 1.28), "jit60x120": jit_grid(1.2, 2.4),
-            "ra5e3_2sgts": ra_sgts(5.0e3, 2), "ra5e4_5sgts": ra_sgts(5.0e4, 5), "ra1e4_7sgts": ra_sgts(1.0e4, 7),
+            "ra2e4_2sgts": ra_sgts(2.0e4, 2), "ra5e4_5sgts": ra_sgts(5.0e4, 5), "ra1e4_7sgts": ra_sgts(1.0e4, 7),
             "mixing_full_b512": mixing_full(), "episode24_b512": episode()}
 
 
-@pytest.mark.parametrize("name", ["jit75x50", "jit110x64", "jit60x120", "ra5e3_2sgts", "ra5e4_5sgts", "ra1e4_7sgts",
+@pytest.mark.parametrize("name", ["jit75x50", "jit110x64", "jit60x120", "ra2e4_2sgts", "ra5e4_5sgts", "ra1e4_7sgts",
                                   "mixing_full_b512", "episode24_b512"])
 def test_float32_stop_rule_on_more_workloads(name):
     """The float32 default (conv_plan 3: the extrapolating plan, guarded; speculative jump for rayleigh) on workloads the
-    first plan test does not reach: three on-demand grids (75x50, 110x64, 60x120), Ra = 5e3 / 5e4 / 1e4 with 2 / 5 / 7
+    first plan test does not reach: three on-demand grids (75x50, 110x64, 60x120), Ra = 2e4 / 5e4 / 1e4 with 2 / 5 / 7
     bottom segments, a FULL 250-timestep mixing step at B=512 through the ticket scheduler, and the 24-step episode with
-    staggered auto-resets.  For each: (a) verify_conv evaluates every sweep and must not flag BCN_ST_PLAN, (b) sweep counts,
-    fields and observations equal, bit for bit, those of conv_plan 0 (every sweep evaluated, as rayleigh.py:448-454 does)
-    and of the run without the speculative jump, (c) no late stop is counted (bcn_get_counters), so nothing was repeated
-    under the proven plan either."""
+    staggered auto-resets.  For each:
+    (a) sweep counts, fields and observations of the default equal, BIT FOR BIT, those of conv_plan 0 (every sweep
+        evaluated, as rayleigh.py:448-454 does), of the proven plan 1 and of the run without the speculative jump;
+    (b) verify_conv (every sweep evaluated next to the plan) gives the same, and flags BCN_ST_PLAN only in replicas whose
+        late-stop counter is non-zero, i.e. every stop the extrapolation did not foresee was caught by the guard and
+        repeated under the proven plan;
+    (c) the UNGUARDED extrapolation (conv_plan 2, round 2's default) never stops early, and differs from the reference's
+        stop sweep only in replicas with late stops -- where there are none it is bit-identical too."""
     make, drive = _plan_workloads()[name]
 
     def run(**opts):
@@ -640,22 +647,35 @@ def test_float32_stop_rule_on_more_workloads(name):
         for k, v in opts.items():
             env.set_option(k, v)
         sw = drive(env)
-        st = env.check_status()
-        out = (sw, env.get_state().clone(), env.obs.clone(), st.copy(), env.get_counters())
+        torch.cuda.synchronize()
+        st = env.status.cpu().numpy().copy()
+        assert not (st & 1).any()                                           # no overflow
+        out = (sw, env.get_state().clone(), env.obs.clone(), st, env.get_counters())
         env.close()
         return out
 
-    default = run()
-    assert int(default[3].max()) == 0
-    assert int(default[4][:, 2].sum()) == 0, "late stops on %s: %d" % (name, int(default[4][:, 2].sum()))
-    variants = {"verify": dict(verify_conv=1), "literal": dict(conv_plan=0), "nojump": dict(spec_start=0),
-                "plan2": dict(conv_plan=2), "proven": dict(conv_plan=1)}
-    for tag, opts in variants.items():
+    def same(a, b):
+        return all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+    default, literal = run(), run(conv_plan=0)
+    assert int(default[3].max()) == 0 and int(literal[3].max()) == 0
+    assert same(default, literal), name
+    for tag, opts in {"nojump": dict(spec_start=0), "proven": dict(conv_plan=1)}.items():
         got = run(**opts)
-        assert int(got[3].max()) == 0, (name, tag, got[3].max())            # no BCN_ST_PLAN, no overflow
-        for a, b in zip(default[0], got[0]):
-            assert torch.equal(a, b), (name, tag, "sweep counts")
-        assert torch.equal(default[1], got[1]) and torch.equal(default[2], got[2]), (name, tag)
+        assert int(got[3].max()) == 0 and same(default, got), (name, tag)
+    ver = run(verify_conv=1)
+    assert same(default, ver), name
+    flagged = (ver[3] & 4) != 0
+    assert not (flagged & (ver[4][:, 2] == 0)).any(), (name, "a skipped sweep passed and the guard did not see it")
+    late = default[4][:, 2]
+    plan2 = run(conv_plan=2)
+    assert int(plan2[3].max()) == 0
+    for a, b in zip(plan2[0], literal[0]):
+        assert int((a < b).sum()) == 0, (name, "the extrapolating plan stopped early")
+    if int(late.sum()) == 0:
+        assert same(plan2, literal), name
+    print("%s: late stops in the last step %d (replicas %d of %d), repeated timesteps %d"
+          % (name, int(late.sum()), int((late > 0).sum()), late.size, int(default[4][:, 3].sum())))
 
 
 @pytest.mark.parametrize("kind", ["rayleigh", "mixing"])
@@ -683,8 +703,15 @@ def test_conv_plan_3_repeats_late_stops_under_the_proven_plan(kind):
         env.close()
         return out
     literal, plan2, plan3 = run(0, 0), run(2, 12), run(3, 12)
-    assert int(plan2[2][:, 2].sum()) > 0 and int((plan2[0] > literal[0]).sum()) > 0      # the hook does provoke late stops
-    assert int((plan2[0] < literal[0]).sum()) == 0                                       # late, never early
+    assert int(plan2[2][:, 2].sum()) > 0                                                 # the hook does provoke late stops
+    p2, lit = plan2[0].cpu().numpy(), literal[0].cpu().numpy()
+    nlate = 0
+    for b in range(lit.shape[0]):                       # a replica's FIRST differing solve is a late one (never early);
+        d = np.nonzero(p2[b] != lit[b])[0]              # behind it the fields differ by a few sweeps' worth of phi
+        if len(d):
+            assert p2[b, d[0]] > lit[b, d[0]], (b, d[0], p2[b, d[0]], lit[b, d[0]])
+            nlate += 1
+    assert nlate > 0
     assert int(plan3[2][:, 2].sum()) > 0 and int(plan3[2][:, 3].sum()) >= int(plan3[2][:, 2].sum())
     assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
 
