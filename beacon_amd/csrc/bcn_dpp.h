@@ -37,6 +37,24 @@ __device__ __forceinline__ float add_above_below(float acc, float c) {
       : "v"(c), "v"(acc));
   return r;
 }
+// One Jacobi cell of the one-row-per-lane kernels with dx == dy, as ONE statement: cx * ((e + w) + north + south) + (cBy * c + nb).
+// The same operations in the same order as the separate statements (results are bit-identical), but hipcc can no longer
+// re-order WITHIN the cell: left to itself it sometimes hoists the q-fma in front of the DPP pair and then has to put an
+// `s_nop 0` between the second DPP add and the fma that consumes it (DPP result -> VALU read), and the whole double sweep
+// came out anywhere between 817 and 895 cycles depending on unrelated code around the loop.  The q-fma sits between the
+// DPP pair and its consumer, where it fills that wait state for free.
+__device__ __forceinline__ float jacobi_cell_eq(float c, float e, float wv, float nbk, float cx, float cBy) {
+  float t, t2, q, ph;
+  asm("v_add_f32 %0, %5, %6\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %4, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %4, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fma_f32 %2, %9, %4, %7\n\t"
+      "v_fma_f32 %3, %8, %0, %2"
+      : "=&v"(t), "=&v"(t2), "=&v"(q), "=v"(ph)
+      : "v"(c), "v"(e), "v"(wv), "v"(nbk), "v"(cx), "v"(cBy));
+  return ph;
+}
 __device__ __forceinline__ double add_above_below(double acc, double c) {
   return acc + dpp<0x130, 0xf, 0xf, true>(0.0, c) + dpp<0x138, 0xf, 0xf, true>(0.0, c);
 }

@@ -621,7 +621,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     auto cell = [&](real c, real e, real wv, real nbk) -> real {
       const real q = cBy * c + nbk;                       // Neumann ghosts in y copy the cell itself
       real ph;
-      if (EQ) {
+      if constexpr (EQ && std::is_same<real, float>::value) {
+        ph = jacobi_cell_eq(c, e, wv, nbk, cx, cBy);       // the whole cell as one statement (bcn_dpp.h)
+      } else if (EQ) {
         real sum = e + wv;
         sum = add_above_below(sum, c);                    // + north (lane+1) + south (lane-1); 0 outside the wave
         ph = cx * sum + q;
