@@ -89,7 +89,7 @@ struct FastGeom {
   // [3][R][64] elements behind everything else (fast_body)
   static constexpr size_t SCR = 3 * (size_t)R * 64;
   template <typename real> static constexpr bool offload() {
-    return NW >= 3 && (base_elems() + SCR) * sizeof(real) <= 160 * 1024;
+    return NW >= 3 && (R + 3) / 4 <= NW - 1 && (base_elems() + SCR) * sizeof(real) <= 160 * 1024;
   }
   template <typename real> static constexpr size_t lds_bytes() {
     return (base_elems() + (offload<real>() ? SCR : 0)) * sizeof(real);
@@ -502,14 +502,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       // strip 0 for wave 0, in chunks of four columns dealt to the helper waves (in an 8-wave workgroup wave 4 shares its
       // SIMD with wave 0: it comes last)
       if (have_pred && have_chain && w != 0) {
+        // (ONE copy of the chunk code, the chunk a run-time index: the kernel has to stay inside the instruction cache)
         constexpr int CH0 = 4, NCH0 = (R0 + CH0 - 1) / CH0;
-        const int rank = (NW == 8) ? (w < 4 ? w - 1 : (w == 4 ? 6 : w - 2)) : w - 1;
-#pragma unroll
-        for (int c = 0; c < NCH0; c++) {
-          if (c % (NW - 1) != rank) continue;
-          __builtin_amdgcn_sched_barrier(0);
+        static_assert(NCH0 <= NW - 1, "one chunk of strip 0 per helper wave");
+        const int c = (NW == 8) ? (w < 4 ? w - 1 : (w == 4 ? 6 : w - 2)) : w - 1;
+        if (c < NCH0) {
+          const int kc = c * CH0;                   // first column of the chunk inside strip 0
           real ur[CH0 + 2], uS[CH0 + 1], uN[CH0], vr[CH0 + 2], vN[CH0 + 1], vS[CH0], pp[CH0 + 1];
-          const int ic = 1 + c * CH0;
+          const int ic = 1 + kc;
 #pragma unroll
           for (int k = 0; k < CH0 + 2; k++) { ur[k] = Ul[(ic - 1 + k) * SY + j]; vr[k] = Vl[(ic - 1 + k) * SY + j]; }
 #pragma unroll
@@ -518,20 +518,23 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
           for (int k = 0; k < CH0; k++) { uN[k] = Ul[(ic + k) * SY + j + 1]; vS[k] = Vl[(ic + k) * SY + j - 1]; }
 #pragma unroll
           for (int k = 0; k <= CH0; k++) {
-            const int kk = c * CH0 + k - 1;          // p column of strip 0 (-1: the wall, no pressure gradient there)
-            pp[k] = (kk >= 0 && kk < R0) ? P0[(kk >= 0 && kk < R0 ? kk : 0) * 64 + lane] : real(0);
+            const int kk = kc + k - 1;               // p column of strip 0 (-1: the wall, no pressure gradient there)
+            const int kq = kk < 0 ? 0 : (kk < R0 ? kk : R0 - 1);
+            const real pv = P0[kq * 64 + lane];
+            pp[k] = (kk >= 0 && kk < R0) ? pv : real(0);
           }
 #pragma unroll
           for (int k = 0; k < CH0; k++) {
-            const int kk = c * CH0 + k;
-            if (kk >= R0) continue;
+            const int kk = kc + k;                   // (columns past the strip, in its last chunk, are computed and dropped)
             const real pc = pp[k + 1];
             const real pS = from_below(pc, pc);
             real uo, xo;
             pred(ic + k, ur[k + 1], ur[k + 2], ur[k], uN[k], uS[k], uS[k + 1], vr[k + 1], vr[k + 2], vr[k], vN[k + 1], vS[k], vN[k],
                  pc, pp[k], pS, uo, xo);
-            US0[(kk < R0 ? kk : 0) * 64 + lane] = uo;
-            VX0[(kk < R0 ? kk : 0) * 64 + lane] = xo;
+            if (kk < R0) {
+              US0[kk * 64 + lane] = uo;
+              VX0[kk * 64 + lane] = xo;
+            }
           }
         }
       }
