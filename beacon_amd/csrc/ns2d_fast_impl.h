@@ -69,14 +69,14 @@ struct FastGeom {
   // u and v of a cell (the same index in two consecutive arrays) with ONE ds_read2st64_b32
   static constexpr int SZ = (SX * SY + 16 + 63) / 64 * 64;
   static constexpr int PD = GF ? BCN_PDG : 4;   // transport prefetch depth (diagonals); deeper for global fields
-  // LDS map (elements): [ exchange 2*NW*2*64 | errp 64 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
+  // LDS map (elements): [ exchange 2*NW*2*64 | errp 128 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
   // columns per strip in the exchange buffer: 0, 1, R-2, R-1 (depth-2 halos: two sweeps per barrier), or the two edge
   // columns only where LDS is short (GF == 2: two float64 fields in LDS)
   static constexpr int XC = (GF == 2) ? 2 : 4;
   static constexpr int EXCH = 2 * NW * XC * 64;             // [2 buffers][NW][XC][64]
-  static constexpr int MISC = EXCH + 160 + 16;              // + 16: scheduler words (ns2d_fast_sched)
+  static constexpr int MISC = EXCH + 224 + 16;              // + 16: scheduler words (ns2d_fast_sched)
   static constexpr int FRONT = ((MISC > 63 * SY + 1 ? MISC : 63 * SY + 1) + 15) / 16 * 16;
   static constexpr int BACK = (NY + 3 * PD + 2) * SY;   // the transport wave prefetches two blocks of PD diagonals ahead
   static constexpr int FRONTG = (63 * SY + 1 + 15) / 16 * 16;          // front pad of the global variant
@@ -276,8 +276,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   constexpr int R = RW;
   constexpr int NW = G::NW, NT = G::NT, SY = G::SY, SX = G::SX, SZ = G::SZ, PD = G::PD;
   real* exch = reinterpret_cast<real*>(smem);  // [2][NW][2][64]
-  real* errp = exch + G::EXCH;                 // [2][2][16]: reference norm / unweighted norm partials
-  real* sact = errp + 64;                      // [64]
+  real* errp = exch + G::EXCH;                 // [2][4][16]: partials of the reference norm / the unweighted norm (x 2 sweeps)
+  real* sact = errp + 128;                     // [64]
   real* red = sact + 64;                       // [32]
   real* gscr = GF ? A.fscr + (size_t)blockIdx.x * A.fscr_stride + G::FRONTG : nullptr;
   real* Ul = GF == 1 ? gscr : GF == 2 ? exch + G::MISCA : exch + G::FRONT;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     Tl[ii * SY + jj] = gS[c];
   }
   for (int c = SX * SY + tid; c < SZ; c += NT) { Ul[c] = 0; Vl[c] = 0; Tl[c] = 0; }
-  if (tid < 64) errp[tid] = 0;
+  if (tid < 128) errp[tid] = 0;
   real p[R];
 #pragma unroll
   for (int k = 0; k < R; k++) p[k] = active ? gp[j * SX + i0 + k] : real(0);
@@ -743,16 +743,16 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
       const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
       const real tot63 = wave_sum_lane63<real>(part);                                        \
-      if (lane == 63) errp[xb * 32 + w] = tot63;                                             \
+      if (lane == 63) errp[xb * 64 + w] = tot63;                                             \
       if (plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
         const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + dl * dl);                  \
-        if (lane == 63) errp[xb * 32 + 16 + w] = totu63;                                     \
+        if (lane == 63) errp[xb * 64 + 16 + w] = totu63;                                     \
       }                                                                                      \
       __syncthreads();                                                                       \
       itp++;                                                                                 \
       /* one read: lane q holds wave q's partial of the reference norm, lane 16 + q that of the unweighted norm; \
          summed in a fixed order, uniformly in every lane */                                 \
-      const real epart = errp[xb * 32 + (lane & 31)];                                        \
+      const real epart = errp[xb * 64 + (lane & 31)];                                        \
       BCN_HALO_READS                                                                         \
       const real esum = row16_sum<real>(epart);                                              \
       const real err = read_lane(esum, 15);                                                  \
@@ -790,6 +790,116 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         if (A.verify_conv) skip_left = j; else n = j;                                        \
       }                                                                                      \
     }
+    // TWO evaluated sweeps (X -> Y -> X) behind ONE barrier and ONE decision: the double sweep above with the residual of
+    // both of its sweeps -- the arithmetic of BCN_CHECK in the same order, so the norms are bit for bit those of two single
+    // evaluated sweeps -- whose partials travel in one LDS word each (lane q / 16 + q: wave q's partial of the reference
+    // norm of the first / second sweep; 32 + q / 48 + q: of the unweighted norm) and come back with one read and one
+    // row sum.  An evaluated single sweep costs 2.6 fast ones (1 816 against 700 cycles: the chain residual -> wave
+    // reduction -> LDS -> barrier -> LDS -> row sum -> decision -> plan is serial); the pair pays that chain once.  If the
+    // first sweep passes, Y is the result (X holds one sweep more, which nothing reads).  The decay factor of the plan is
+    // that of the pair itself: the most recent -- by log-convexity the largest -- lower bound of every later factor.
+#define BCN_CHECK2X(X, Y)                                                                    \
+    {                                                                                        \
+      const int itp0 = itp;                                                                  \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) Y[k] = cell(X[k], X[k + 1], X[k - 1], nb[k]); \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      const real xw1 = (w > 0) ? hW1r : X[0], xe1 = (w < NW - 1) ? hE1r : X[R - 1];          \
+      Y[0] = cell(X[0], X[1], xw1, nb[0]);                                                   \
+      Y[R - 1] = cell(X[R - 1], xe1, X[R - 2], nb[R - 1]);                                   \
+      real yw = cell(hW1r, X[0], hW2r, nbW), ye = cell(hE1r, hE2r, X[R - 1], nbE);           \
+      yw = (w > 0) ? yw : Y[0];                                                              \
+      ye = (w < NW - 1) ? ye : Y[R - 1];                                                     \
+      BCN_NCHK_INC BCN_NCHK_INC                                                              \
+      real acc1 = 0;                                                                         \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) { const real d = Y[k] - X[k]; acc1 += d * d; } \
+      const real d10 = Y[0] - X[0], d1l = Y[R - 1] - X[R - 1];                               \
+      const real part1 = wl * acc1 + cW * (d10 * d10) + cE * (d1l * d1l);                    \
+      const real upart1 = acc1 + d10 * d10 + d1l * d1l;                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      X[0] = cell(Y[0], Y[1], yw, nb[0]);                                                    \
+      X[1] = cell(Y[1], Y[2], Y[0], nb[1]);                                                  \
+      X[R - 2] = cell(Y[R - 2], Y[R - 1], Y[R - 3], nb[R - 2]);                              \
+      X[R - 1] = cell(Y[R - 1], ye, Y[R - 2], nb[R - 1]);                                    \
+      hW = yw; hE = ye;                                                                      \
+      BCN_PUBLISH(X)                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      _Pragma("unroll") for (int k = 2; k < R - 2; k++) X[k] = cell(Y[k], Y[k + 1], Y[k - 1], nb[k]); \
+      real acc2 = 0;                                                                         \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) { const real d = X[k] - Y[k]; acc2 += d * d; } \
+      const real d20 = X[0] - Y[0], d2l = X[R - 1] - Y[R - 1];                               \
+      const real part2 = wl * acc2 + cW * (d20 * d20) + cE * (d2l * d2l);                    \
+      const real t1_63 = wave_sum_lane63<real>(part1), t2_63 = wave_sum_lane63<real>(part2); \
+      if (lane == 63) { errp[xb * 64 + w] = t1_63; errp[xb * 64 + 16 + w] = t2_63; }         \
+      if (plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
+        const real u1_63 = wave_sum_lane63<real>(upart1);                                    \
+        const real u2_63 = wave_sum_lane63<real>(acc2 + d20 * d20 + d2l * d2l);              \
+        if (lane == 63) { errp[xb * 64 + 32 + w] = u1_63; errp[xb * 64 + 48 + w] = u2_63; }  \
+      }                                                                                      \
+      __syncthreads();                                                                       \
+      itp += 2;                                                                              \
+      const real epart = errp[xb * 64 + lane];                                               \
+      BCN_HALO_READS                                                                         \
+      const real esum = row16_sum<real>(epart);                                              \
+      const real err1 = read_lane(esum, 15), err2 = read_lane(esum, 31);                     \
+      const bool pass1 = !(err1 > A.tol), pass2 = !(err2 > A.tol);                           \
+      /* behind the speculative jump the proven plan also needs the unweighted norm above its threshold */ \
+      const bool amb = SPEC && skip_left == -2 && plan == 1 && !(read_lane(esum, 47) > A.tol * real(1.02)); \
+      if (pass1 || pass2 || amb) {                                                           \
+        if (skip_left > (pass1 ? 0 : 1)) status |= BCN_ST_PLAN;   /* verify_conv: a sweep the plan skips passes */ \
+        if (SPEC) skip_left = skip_left == -2 ? -1 : 0;                                      \
+        finalB = pass1;                                                                      \
+        itp -= pass1 ? 1 : 0;                                                                \
+        /* the first sweep was the last one: the west halo of ITS result is the neighbour's edge column as recomputed here */ \
+        hW1r = pass1 ? yw : hW1r;                                                            \
+        /* a stop the plan did not foresee: the passing sweep directly follows skipped ones */ \
+        late_stop = pass1 && itp0 > 0 && k_prev != itp0;                                     \
+        break;                                                                               \
+      }                                                                                      \
+      if (SPEC) skip_left = skip_left < 0 ? 0 : skip_left;                                   \
+      if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = false; break; }                  \
+      n = 0;                                                                                 \
+      if (skip_left > 0) {                                                                   \
+        skip_left = skip_left > 2 ? skip_left - 2 : 0;                                       \
+      } else if (plan > 0) {   /* plan the next evaluation (see above) */                    \
+        int j = 0;                                                                           \
+        if (plan == 1) {                                                                     \
+          const float l2u1 = __log2f((float)read_lane(esum, 47)), l2u2 = __log2f((float)read_lane(esum, 63)); \
+          const float room_u = l2u2 - l2tol_u, rho_u = l2u2 - l2u1;                          \
+          if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
+        } else {                                                                             \
+          const float l2w1 = __log2f((float)err1), l2w2 = __log2f((float)err2);              \
+          const float room_w = l2w2 - l2tol_w, rho_w = l2w2 - l2w1;                          \
+          int jw = 0;                                                                        \
+          if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
+          j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                         \
+          j = j > 0 ? j : 0;                                                                 \
+        }                                                                                    \
+        j = __builtin_amdgcn_readfirstlane(j) & ~1;                                          \
+        k_prev = itp;                                                                        \
+        if (A.verify_conv) skip_left = j; else n = j;                                        \
+      }                                                                                      \
+    }
+    // Measured on the float32 128x64 kernel: plans 0 and 1, which evaluate runs of consecutive sweeps (all of them / the last
+    // ~20 of a solve), gain from pairs -- 1 417 instead of 1 816 cycles per evaluated sweep, plan 1 1 006 instead of 1 133 per
+    // sweep on average; the extrapolating plans evaluate mostly isolated sweeps, where an evaluated single sweep followed by
+    // a fast one is what a pair costs (813 against 801), and carrying both loops in one kernel slowed the default by 2 %.
+    // So the choice is by instantiation: float64, whose default is the proven plan, evaluates in pairs; float32, whose
+    // default extrapolates, keeps single evaluations.
+    constexpr bool PAIRS = XC == 4 && !std::is_same<real, float>::value;
+    bool late_stop = false;
+    if constexpr (PAIRS) {
+      for (;;) {
+        int n;
+        BCN_CHECK2X(phA, phB)
+        if (SPEC && itp == 2 && A.spec_start > 0 && plan > 0 && !A.verify_conv) {   // first pair: the speculative jump
+          const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
+          const int ns = ((prev * A.spec_start) >> 3) - 2;
+          if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }
+        }
+        if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
+        for (; n > 0; n -= 2) BCN_FAST2X(phA, phB)
+      }
+    } else {
     for (;;) {
       int n;
       BCN_CHECK(phA, phB, true)
@@ -815,6 +925,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         }
       }
     }
+    late_stop = itp >= 2 && k_prev != itp - 2;   // (single evaluated sweeps: k_prev is the index of the one before the last)
+    }
+#undef BCN_CHECK2X
 #undef BCN_CHECK
 #undef BCN_FAST2X
 #undef BCN_HALO_READS
@@ -829,7 +942,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       // (bcn_get_counters).  conv_plan 3 repeats such a solve under the proven plan 1, as a jump that went too far
       // (skip_left == -1) repeats it without the guess.
       const bool toofar = SPEC && skip_left == -1;
-      const bool late = plan >= 2 && !toofar && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
+      const bool late = plan >= 2 && !toofar && late_stop && !(status & BCN_ST_ITMAX);
       if (late && tid == 0) prev_sweeps[2] += 1;
       if (!(toofar || (late && A.conv_plan == 3))) {
         if (tid == 0) { prev_sweeps[0] = SPEC ? (real)itp : real(0); prev_sweeps[1] = 0; }
@@ -982,7 +1095,7 @@ __global__ BCN_KERNEL_ATTR __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_body's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
-                                                          FastGeom<NX, NY, R, GF>::EXCH + 160);
+                                                          FastGeom<NX, NY, R, GF>::EXCH + 224);
   ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
     fast_unit<real, NX, NY, R, KIND, EQ, GF>(A, b, it0, it1, first, last, smem);
   });
