@@ -92,9 +92,11 @@ struct NS2DEnv : bcn_env_s {
     // did not foresee is repeated under the proven plan (ns2d_fast_impl.h)
     a.conv_plan = sizeof(real) == 4 ? 3 : 1;
     if (const char* e = getenv("BCN_CONV_PLAN")) a.conv_plan = atoi(e);
-    // rayleigh float32: consecutive timesteps never differed by more than 30 % (611 000 solves); mixing's do; the float64
+    // rayleigh float32: a solve opens with double sweeps up to 7/8 of the previous timestep's count (measured on the bench
+    // workload: 5/8, 6/8, 7/8 -> 800, 791, 778 cycles per sweep; at 7/8 about 30 of 102 400 solves per step land behind
+    // their stop sweep and are repeated); mixing's counts drop by up to 9x from one timestep to the next: off; the float64
     // kernels are built without the jump (ns2d_fast_impl.h)
-    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 6 : 0;
+    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 7 : 0;
     if (const char* e = getenv("BCN_SPEC_START")) a.spec_start = atoi(e);
     return BCN_OK;
   }

@@ -909,6 +909,21 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         for (; n > 0; n -= 2) BCN_FAST2X(phA, phB)
       }
     } else {
+    // Speculative jump (see above), taken at once: with a previous count to go by, the solve OPENS with double sweeps up to
+    // spec_start/8 of it and evaluates the residual there for the first time -- sweeps 1 and 2, evaluated only to start the
+    // plan, cost two of the solve's ~9 evaluations (an evaluated sweep costs 2.6 fast ones).  If that first evaluation
+    // fails, no earlier sweep passed; if it passes, the solve is repeated without the guess.
+    if constexpr (SPEC && XC == 4) {
+      if (A.spec_start > 0 && plan > 0 && !A.verify_conv) {
+        const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
+        int n0 = ((prev * A.spec_start) >> 3) & ~1;
+        if (n0 > A.itmax) n0 = A.itmax & ~1;
+        if (prev >= 16 && n0 > 0) {
+          skip_left = -2;
+          for (; n0 > 0; n0 -= 2) BCN_FAST2X(phA, phB)
+        }
+      }
+    }
     for (;;) {
       int n;
       BCN_CHECK(phA, phB, true)
@@ -919,7 +934,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         BCN_FAST(phB, phA)
         n = (n - 1) & ~1;
       }
-      if (SPEC && itp == 2 && A.spec_start > 0 && plan > 0 && !A.verify_conv) {   // first pass: the speculative jump
+      if (SPEC && XC != 4 && itp == 2 && A.spec_start > 0 && plan > 0 && !A.verify_conv) {   // (single-sweep exchange: behind sweeps 1, 2)
         const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
         const int ns = ((prev * A.spec_start) >> 3) - 2;
         if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }

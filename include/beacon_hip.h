@@ -197,11 +197,12 @@ BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_ele
  *                 late stop is repeated under plan 1 (default for BCN_F32; see ns2d_fast_impl.h)
  *   "plan_overshoot" 0..64, TEST HOOK: lengthens every skip of plans 2 / 3 by that many sweeps, so that late stops occur
  *   "verify_conv" 1 = evaluate every sweep anyway and raise BCN_ST_PLAN if a sweep the plan skips passes the test
- *   "spec_start"  0..16: behind the evaluations of sweeps 1 and 2, place the next evaluation at spec_start/8 of the
- *                 previous timestep's sweep count; if that evaluation passes, the timestep is repeated without the guess.
+ *   "spec_start"  0..16: open a solve with unevaluated double sweeps up to spec_start/8 of the previous timestep's sweep
+ *                 count and evaluate the residual there for the first time; if that evaluation passes, the solve is
+ *                 repeated without the guess.
  *                 Under plan 1 the jump is proven (the unweighted norm never increases and must still exceed the
  *                 tolerance there); under plans 2 / 3 it relies on the same observed monotonicity of the reference's
- *                 norm as the plan itself.  BCN_F32 rayleigh only (default 6); ignored by BCN_F64 handles, off for mixing
+ *                 norm as the plan itself.  BCN_F32 rayleigh only (default 7); ignored by BCN_F64 handles, off for mixing
  * Returns BCN_ERR_ARG for unknown names. */
 BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference
