@@ -888,33 +888,19 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         if (A.verify_conv) skip_left = j; else n = j;                                        \
       }                                                                                      \
     }
-    // Measured on the float32 128x64 kernel: plans 0 and 1, which evaluate runs of consecutive sweeps (all of them / the last
-    // ~20 of a solve), gain from pairs -- 1 417 instead of 1 816 cycles per evaluated sweep, plan 1 1 006 instead of 1 133 per
-    // sweep on average; the extrapolating plans evaluate mostly isolated sweeps, where an evaluated single sweep followed by
-    // a fast one is what a pair costs (813 against 801), and carrying both loops in one kernel slowed the default by 2 %.
-    // So the choice is by instantiation: float64, whose default is the proven plan, evaluates in pairs; float32, whose
-    // default extrapolates, keeps single evaluations.
-    constexpr bool PAIRS = XC == 4 && !std::is_same<real, float>::value;
+    // Evaluations come in pairs wherever the exchange carries depth-2 halos (XC == 4).  Measured on the float32 128x64 kernel,
+    // cycles per sweep on average: plan 0 1 816 -> 1 417, plan 1 1 133 -> 1 006; the default (plan 3 with the jump at the
+    // start of the solve, whose landing is two consecutive evaluations anyway) 778 -> 740.
+    constexpr bool PAIRS = XC == 4;
     bool late_stop = false;
-    if constexpr (PAIRS) {
-      for (;;) {
-        int n;
-        BCN_CHECK2X(phA, phB)
-        if (SPEC && itp == 2 && A.spec_start > 0 && plan > 0 && !A.verify_conv) {   // first pair: the speculative jump
-          const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
-          const int ns = ((prev * A.spec_start) >> 3) - 2;
-          if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }
-        }
-        if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
-        for (; n > 0; n -= 2) BCN_FAST2X(phA, phB)
-      }
-    } else {
     // Speculative jump (see above), taken at once: with a previous count to go by, the solve OPENS with double sweeps up to
     // spec_start/8 of it and evaluates the residual there for the first time -- sweeps 1 and 2, evaluated only to start the
     // plan, cost two of the solve's ~9 evaluations (an evaluated sweep costs 2.6 fast ones).  If that first evaluation
     // fails, no earlier sweep passed; if it passes, the solve is repeated without the guess.
     if constexpr (SPEC && XC == 4) {
-      if (A.spec_start > 0 && plan > 0 && !A.verify_conv) {
+      // (extrapolating plans only: the proven plan must find the UNWEIGHTED norm above the tolerance where it lands, which
+      // at 7/8 of the previous count it almost never is -- measured: nearly every solve repeated)
+      if (A.spec_start > 0 && plan > 1 && !A.verify_conv) {
         const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
         int n0 = ((prev * A.spec_start) >> 3) & ~1;
         if (n0 > A.itmax) n0 = A.itmax & ~1;
@@ -924,6 +910,14 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         }
       }
     }
+    if constexpr (PAIRS) {
+      for (;;) {
+        int n;
+        BCN_CHECK2X(phA, phB)
+        if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps
+        for (; n > 0; n -= 2) BCN_FAST2X(phA, phB)
+      }
+    } else {
     for (;;) {
       int n;
       BCN_CHECK(phA, phB, true)

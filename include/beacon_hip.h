@@ -200,9 +200,10 @@ BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_ele
  *   "spec_start"  0..16: open a solve with unevaluated double sweeps up to spec_start/8 of the previous timestep's sweep
  *                 count and evaluate the residual there for the first time; if that evaluation passes, the solve is
  *                 repeated without the guess.
- *                 Under plan 1 the jump is proven (the unweighted norm never increases and must still exceed the
- *                 tolerance there); under plans 2 / 3 it relies on the same observed monotonicity of the reference's
- *                 norm as the plan itself.  BCN_F32 rayleigh only (default 7); ignored by BCN_F64 handles, off for mixing
+ *                 Plans 2 / 3 only: the jump relies on the same observed monotonicity of the reference's norm as those
+ *                 plans themselves (the proven plan 1 would have to find the unweighted norm above the tolerance where
+ *                 it lands, which it almost never is).  BCN_F32 rayleigh only (default 7); ignored by BCN_F64 handles,
+ *                 off for mixing
  * Returns BCN_ERR_ARG for unknown names. */
 BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference

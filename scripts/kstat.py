@@ -2,6 +2,11 @@
 # the solve (bcn_get_counters), late stops / repeats.  usage: python scripts/kstat.py [dtype] [steps] [opt=value ...]
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
+defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+sys.argv = [a for a in sys.argv if not a.startswith("-D")]
+if defs:                                           # experiment build: python scripts/kstat.py f32 6 -DBCN_SOMETHING=1
+    from beacon_amd import build
+    build.FLAGS.extend(defs); build.build_lib(force=True)
 from beacon_amd import vec as V
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -27,5 +32,5 @@ for k in range(steps):
     cj += c[:, 0].sum(); ct += c[:, 1].sum(); sw += float(env.sweeps.sum())
 env.check_status()
 nts = steps * B * env.ndt_act
-print("%s %s B=%d: %.2f ms/step (min %.2f)  sweeps/dt %.1f  cycles/sweep %.0f  cycles/timestep outside the solve %.0f  jacobi share %.3f  late %d repeats %d"
+print(" ".join(defs), "%s %s B=%d: %.2f ms/step (min %.2f)  sweeps/dt %.1f  cycles/sweep %.0f  cycles/timestep outside the solve %.0f  jacobi share %.3f  late %d repeats %d"
       % (env.kernel_name, dtype, B, np.mean(ms), np.min(ms), sw / nts, cj / sw, (ct - cj) / nts, cj / ct, int(c[:, 2].sum()), int(c[:, 3].sum())))
