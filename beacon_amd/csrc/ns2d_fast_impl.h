@@ -43,6 +43,10 @@
 #ifndef BCN_PDG
 #define BCN_PDG 12   // global fields: 4 / 8 / 12 diagonals ahead: 52.9 / 52.1 / 51.3 ms per step (rayleigh 128x64 float64)
 #endif
+#ifndef BCN_PDF
+#define BCN_PDF 8    // fields in LDS: diagonals per block of the transport wave (two register sets: it runs PDF..2 PDF diagonals ahead;
+                     // measured 4 / 6 / 8 / 12 / 16: 26.2 / 25.7 / 24.8 / 25.3 / 26.3 k cycles per timestep outside the solve)
+#endif
 #ifndef BCN_R128D
 #define BCN_R128D 16   // columns per lane of the float64 128x64 kernel
 #endif
@@ -68,7 +72,7 @@ struct FastGeom {
   // +16: lanes >= NY read (never write) past the array; a multiple of 64 elements, so that the transport wave fetches
   // u and v of a cell (the same index in two consecutive arrays) with ONE ds_read2st64_b32
   static constexpr int SZ = (SX * SY + 16 + 63) / 64 * 64;
-  static constexpr int PD = GF ? BCN_PDG : 4;   // transport prefetch depth (diagonals); deeper for global fields
+  static constexpr int PD = GF ? BCN_PDG : BCN_PDF;   // transport prefetch depth (diagonals); deeper for global fields
   // LDS map (elements): [ exchange 2*NW*2*64 | errp 128 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
   // -62..NX+NY+PD fall into FRONT / the neighbouring arrays / BACK, always inside this allocation.
@@ -117,7 +121,7 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
                                                               float c0y, float c1y) {
   using G = FastGeom<NX, NY, R, 0>;
   constexpr int SY = G::SY, PD = G::PD, NSTEP = NX + NY - 1;
-  static_assert(PD == 4, "block of four diagonals");
+  static_assert(PD % 2 == 0, "blocks of an even number of diagonals (packed coefficient fmas)");
   const int lane = threadIdx.x & 63;
   const int j = lane + 1;
   const bool active = lane < NY;
@@ -140,9 +144,7 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
     const lds_f* const Tq = Tc + (OFF) * SY;                                                  \
     const lds_f* const Uq = Uc + (OFF) * SY;                                                  \
     const lds_f* const Vq = Uq + G::SZ;                                                       \
-    RA[0] = Tq[0]; RA[1] = Tq[SY]; RA[2] = Tq[2 * SY]; RA[3] = Tq[3 * SY];                    \
-    RU[0] = Uq[0]; RU[1] = Uq[SY]; RU[2] = Uq[2 * SY]; RU[3] = Uq[3 * SY];                    \
-    RV[0] = Vq[0]; RV[1] = Vq[SY]; RV[2] = Vq[2 * SY]; RV[3] = Vq[3 * SY];                    \
+    _Pragma("unroll") for (int q = 0; q < PD; q++) { RA[q] = Tq[q * SY]; RU[q] = Uq[q * SY]; RV[q] = Vq[q * SY]; } \
   }
   // MASK 0: every lane inside, or running on behind the domain; 1: lanes <= t; 2: lanes > t - NX; 3: both tests; 4: as 1
   // for NY == 64, by value
@@ -174,7 +176,7 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
       tq[q] = (MASK == 4 && !okq[q]) ? RA[q] : t1;                                            \
     }                                                                                         \
     if (MASK == 0 || MASK == 4) {                                                             \
-      Tq[0] = tq[0]; Tq[SY] = tq[1]; Tq[2 * SY] = tq[2]; Tq[3 * SY] = tq[3];                  \
+      _Pragma("unroll") for (int q = 0; q < PD; q++) Tq[q * SY] = tq[q];                      \
     } else {                                                                                  \
       _Pragma("unroll") for (int q = 0; q < PD; q++) { lds_f* dst = okq[q] ? Tq + q * SY : dummyL; *dst = tq[q]; } \
     }                                                                                         \

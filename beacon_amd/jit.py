@@ -31,7 +31,7 @@ def _lds_rows1(nx, ny, nw, esz, gf):
     sy, sz = ny + 2, ((nx + 2) * (ny + 2) + 16 + 63) // 64 * 64
     misc = 2 * nw * (2 if gf == 2 else 4) * 64 + 224 + 16
     front = _up16(max(misc, 63 * sy + 1))
-    back = (ny + 3 * 4 + 2) * sy
+    back = (ny + 3 * 8 + 2) * sy
     if gf == 1:
         return _up16(misc) * esz
     if gf == 2:
