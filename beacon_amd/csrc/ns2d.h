@@ -51,6 +51,7 @@ struct NS2DArgs {
   unsigned long long* cyc;  // [B][4] of the last step: shader-clock cycles inside the Jacobi loop / in the whole replica, late stops, repeated timesteps (bcn_get_counters)
   size_t sched_bytes;       // bytes of sched_ctl + cyc: zeroed by one memset in front of every step launch
   int sched_q;              // timesteps per chunk
+  int sched_nbig = 0;       // the first sched_nbig chunks of a step are 2 sched_q timesteps long (ns2d_sched.h)
   int conv_plan = 1;        // which Jacobi sweeps evaluate the residual: 0 all, 1 proven skips only, 2 + extrapolated, 3 = 2 with unverified stops repeated under 1 (ns2d_fast_impl.h)
   int plan_overshoot = 0;   // TEST HOOK: sweeps added to every skip of the extrapolating plan (provokes late stops: tests of conv_plan 3)
   int spec_start = 0;       // first evaluation of a solve at spec_start/8 of the previous timestep's sweep count (0: at sweep 1): ns2d_fast_impl.h

@@ -1166,7 +1166,8 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     if (ns2d_first_on_device(attr_set2)) {
       BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    const int nchunk = a.ndt_act / SQ;
+    int nchunk = 0;
+    ns2d_sched_chunks(a.ndt_act, SQ, &c.sched_nbig, &nchunk);
     c.sched_q = SQ; c.order = nullptr; c.first_chunk = 1; c.last_chunk = 1; c.it_begin = 0; c.it_end = a.ndt_act;
     BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
     hipLaunchKernelGGL(ks, dim3(sched_grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);

@@ -62,8 +62,10 @@ __device__ __forceinline__ void ns2d_sched_loop(const NS2DArgs<real>& A, SchedCt
     __syncthreads();
     if (!skip) {
       if (s_ok) {
-        const int it0 = c * A.sched_q;
-        const int it1 = (c == nchunk - 1) ? A.ndt_act : it0 + A.sched_q;
+        // chunk c: the first sched_nbig chunks are twice as long (half the hand-offs through HBM where the order of the
+        // units cannot matter yet), the last ones short (the step ends when the slowest replica's last chunk does)
+        const int it0 = c < A.sched_nbig ? c * 2 * A.sched_q : (c + A.sched_nbig) * A.sched_q;
+        const int it1 = (c == nchunk - 1) ? A.ndt_act : it0 + (c < A.sched_nbig ? 2 : 1) * A.sched_q;
         unit(b, it0, it1, c == 0, c == nchunk - 1);
       } else if (threadIdx.x == 0) {
         A.status[b] = BCN_ST_ITMAX;   // handle-owned when the caller passed none: never NULL here
@@ -94,6 +96,20 @@ inline bool ns2d_first_on_device(unsigned long long& seen) {
 // (default); BCN_SCHED_GRID persistent workgroups (default: one per CU of the handle's device); BCN_SCHED_Q
 // timesteps per chunk.  The environment gives the process-wide defaults; bcn_set_sched() overrides them per
 // handle (NS2DArgs::sched_mode / sched_grid / sched_q_user, -1 / 0 / 0 = default).
+// chunks of one step: nbig long ones (2 q timesteps) followed by short ones (q; the last takes the remainder), the short
+// tail covering at least the last `tail` * q timesteps.  BCN_SCHED_TAIL overrides tail (default 6); a tail >= ndt / q
+// gives uniform chunks.
+inline void ns2d_sched_chunks(int ndt, int q, int* nbig, int* nchunk) {
+  static int tail = -1;
+  if (tail < 0) { const char* e = getenv("BCN_SCHED_TAIL"); tail = e ? atoi(e) : 6; }
+  int nb = (ndt - tail * q) / (2 * q);
+  if (nb < 0) nb = 0;
+  int rem = ndt - nb * 2 * q;
+  int ns = rem / q;
+  if (ns < 1) { ns = 1; }
+  *nbig = nb;
+  *nchunk = nb + ns;
+}
 struct SchedParams {
   int mode, grid, q;
   bool q_set;   // chunk length given (environment or handle): overrides the per-kernel default
