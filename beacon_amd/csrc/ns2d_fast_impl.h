@@ -589,15 +589,6 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         nb[k] = active ? -A.cb * ((ue - us[k]) * rdx + (vn - vs[k]) * rdy) : real(0);
       }
     }
-    // float64: u*, v* wait in LDS, in place of u, v (dead until the corrector rewrites them), instead of in 64 VGPRs across
-    // the Jacobi loop -- phi (ping-pong), the rhs and p are 128 of a float64 thread's 256 already
-    constexpr bool PARK = sizeof(real) == 8 && GF != 1;
-    if constexpr (PARK) {
-      if (active) {
-#pragma unroll
-        for (int k = 0; k < R; k++) { Ul[(i0 + k) * SY + j] = us[k]; Vl[(i0 + k) * SY + j] = vs[k]; }
-      }
-    }
     // rhs of the neighbouring strips' edge columns: the double sweeps below recompute those columns (depth-2 halos)
     const int wm = (w > 0) ? w - 1 : 0, wp = (w < NW - 1) ? w + 1 : NW - 1;
     real nbW = 0, nbE = 0;
@@ -1001,8 +992,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real ps = from_below(ph, ph);
       p[k] += ph;
       if (active) {
-        if (i >= 2) Ul[i * SY + j] = (PARK ? Ul[i * SY + j] : us[k]) - dt * (ph - pw) * rdx;
-        if (j >= 2) Vl[i * SY + j] = (PARK ? Vl[i * SY + j] : vs[k]) - dt * (ph - ps) * rdy;
+        if (i >= 2) Ul[i * SY + j] = us[k] - dt * (ph - pw) * rdx;
+        if (j >= 2) Vl[i * SY + j] = vs[k] - dt * (ph - ps) * rdy;
       }
     }
     __syncthreads();
