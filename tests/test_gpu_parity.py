@@ -363,14 +363,16 @@ def _oracle_batch_step(init, acts, nrep, L=2.56, H=1.28):
     return st[:, :4].reshape(nrep, 4, e.cfg.nx + 2, e.cfg.ny + 2), obs, rwd, sw
 
 
-@pytest.mark.parametrize("dtype,ftol,swtol", [("f32", 5e-5, 3), ("f64", F64_TOL, 1)])
+@pytest.mark.parametrize("dtype,ftol,swtol", [("f32", 1e-5, 3), ("f64", F64_TOL, 1)])
 def test_rayleigh_bench_dispatch_vs_oracle_and_reference(dtype, ftol, swtol):
     """The timed dispatch itself -- B=512, 128x64, 200 timesteps, default scheduler: `ns2d_fast_sched` -- against
     (a) the float64 C oracle on replicas 0..7 over one FULL action step and (b) the reference's own full step for
     replicas 0 and 1 (tests/golden/rayleigh_128x64_step{0,1}.npz, captured by oracle/capture/capture.py).
-    float32 tolerance, stated against the float64 reference: fields/obs 5e-5 absolute (|T| <= 1.25, |u|,|v| < 0.3;
-    measured 4e-6), p 50x that (200 accumulated phi), reward 1e-4, total sweeps of the step within 1 % and per
-    timestep within 3; float64: 1e-9 with equal sweep counts (+-1 at the threshold)."""
+    float32 tolerance, stated against the float64 reference and set from scripts/f32_errors.py (round 3: u, v 4e-7,
+    T and p 1.3e-6, observations 1.2e-6, reward 4e-6, every sweep count equal): fields/obs 1e-5 absolute (|T| <= 1.25,
+    |u|,|v| < 0.3), p 2e-5 (200 accumulated phi), reward 2e-5, total sweeps of the step within 0.2 % and per timestep
+    within 3; float64: 1e-9 with equal sweep counts (+-1 at the threshold)."""
+    pf = 2 if dtype == "f32" else 50        # p: float32 measured (above); float64 keeps the generous factor of 1e-9
     B, NREP = 512, 8
     env, init, acts = _bench_workload(B, 1, dtype)
     obs, rwd, done, trunc, _ = env.step(acts[0])
@@ -383,14 +385,14 @@ def test_rayleigh_bench_dispatch_vs_oracle_and_reference(dtype, ftol, swtol):
     ost, oobs, orwd, osw = _oracle_batch_step(init, acts[0], NREP)
     for b in range(NREP):
         for i, F in enumerate("uvpT"):
-            assert maxdiff(st[b][i], ost[b][i]) <= ftol * (50 if F == "p" else 1), (b, F)
+            assert maxdiff(st[b][i], ost[b][i]) <= ftol * (pf if F == "p" else 1), (b, F)
         assert maxdiff(o[b], oobs[b]) <= ftol and abs(r[b] - orwd[b]) <= max(1e-8, 2 * ftol)
-        assert abs(int(sw[b].sum()) - int(osw[b])) <= max(swtol, 0.01 * osw[b] if dtype == "f32" else 0), (b, sw[b].sum(), osw[b])
+        assert abs(int(sw[b].sum()) - int(osw[b])) <= max(swtol, 0.002 * osw[b] if dtype == "f32" else 0), (b, sw[b].sum(), osw[b])
     for b in (0, 1):                      # the reference itself
         g = golden("rayleigh_128x64_step%d" % b)
         assert np.array_equal(g["action"], acts[0, b])
         for i, F in enumerate("uvpT"):
-            assert maxdiff(st[b][i], g[F]) <= ftol * (50 if F == "p" else 1), (b, F)
+            assert maxdiff(st[b][i], g[F]) <= ftol * (pf if F == "p" else 1), (b, F)
         # the capture steps from loaded fields without reset()'s get_obs: only the newest history slot is comparable
         assert maxdiff(o[b][-96:], g["obs"][-96:]) <= ftol and abs(r[b] - float(g["rwd"])) <= max(1e-8, 2 * ftol)
         assert np.max(np.abs(sw[b] - g["itp"])) <= swtol, (b, np.max(np.abs(sw[b] - g["itp"])))
@@ -420,12 +422,13 @@ def test_rayleigh_bench_dispatch_scheduler_is_bit_exact(dtype):
     assert float((a[3][:, 2] - b[3][:, 2]).abs().max()) < (1e-4 if dtype == "f32" else 1e-12)
 
 
-@pytest.mark.parametrize("dtype,tol,swrel", [("f32", 2e-4, 0.02), ("f64", F64_TOL, 0.0)])
+@pytest.mark.parametrize("dtype,tol,swrel", [("f32", 2e-5, 0.02), ("f64", F64_TOL, 0.0)])
 def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler(dtype, tol, swrel):
     """mixing-v0 at BASELINE configs[4]'s batch: B=512, 100x100, one full 250-timestep step from rest through
     `ns2d_fast2_sched` (256 persistent workgroups): replicas 0..3 (actions 0..3) against the float64 C oracle
-    (float32 tolerance as test_mixing_from_rest_vs_golden: 2e-4, sweeps within 2 %), and the whole batch bit for
-    bit against the unscheduled launch."""
+    (float32 tolerance from scripts/f32_errors.py -- measured u, v, C 2.5e-6, p 1.1e-5, observations 1.2e-6, at most two
+    sweeps' difference in a timestep: 2e-5, p 1e-4, sweeps within 3 or 2 %), and the whole batch bit for bit against the
+    unscheduled launch."""
     B = 512
     a = (np.arange(B) % 4).astype(np.int64)
     outs = []
@@ -450,7 +453,7 @@ def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler(dtype, tol, swrel):
         o.reset()
         ob, rw, _, _, _ = o.step(int(a[b]))
         for i, F in enumerate("uvpC"):
-            assert maxdiff(st[b][i], o.st[i]) <= tol * (50 if F == "p" else 1), (b, F)
+            assert maxdiff(st[b][i], o.st[i]) <= tol * ((5 if dtype == "f32" else 50) if F == "p" else 1), (b, F)
         assert maxdiff(x[0][b].cpu().numpy(), ob) <= tol and abs(float(x[1][b]) - rw) <= max(1e-9, 0.05 * tol)
         assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(1 if dtype == "f64" else 3, swrel * o.itp)), b
         assert torch.equal(x[0][b], x[0][b + 4])          # same action -> same replica, whatever CU ran it
