@@ -842,8 +842,8 @@ int launch_fast2_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     auto ks = ns2d_fast2_sched<real, NX, NY, R, KIND, EQ, GF>;
     static unsigned long long set2 = 0;
     if (ns2d_first_on_device(set2)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int nchunk = 0;
-    ns2d_sched_chunks(a.ndt_act, q, &c.sched_nbig, &nchunk);
+    const int nchunk = a.ndt_act / q;   // uniform chunks (the long-chunks-first order of ns2d_fast_impl.h measured slower here)
+    c.sched_nbig = 0;
     c.sched_q = q;
     BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
     hipLaunchKernelGGL(ks, dim3(sp.grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
