@@ -88,6 +88,7 @@ SIGNATURES = {
     "bcn_get_counters": (C.c_int, [vp, C.POINTER(C.c_uint64), vp]),
     "bcn_set_fast_plugin": (C.c_int, [vp, vp, C.c_size_t]),
     "bcn_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "bcn_set_noise": (C.c_int, [vp, C.c_double, C.c_uint64, C.c_int64]),
     "bcn_set_sched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bcn_kernel_name": (C.c_char_p, [vp]),
     "bcn_destroy": (C.c_int, [vp]),

@@ -65,6 +65,7 @@ struct bcn_env_s {
   virtual void set_mask(const uint8_t* m) = 0;
   virtual int set_sched(int, int, int, int) { return BCN_OK; }
   virtual int set_fast_plugin(void*, size_t) { bcn_set_error("this env takes no kernel plugin"); return BCN_ERR_ARG; }
+  virtual int set_noise(double, uint64_t, int64_t) { bcn_set_error("this env has no inlet noise"); return BCN_ERR_ARG; }
   virtual int set_option(const char* name, int) { bcn_set_error("unknown option '%s' for this env", name); return BCN_ERR_ARG; }
   virtual int get_counters(uint64_t* host, hipStream_t) { memset(host, 0, (size_t)batch * 4 * sizeof(uint64_t)); return BCN_OK; }   // only the 2D register-resident kernels schedule
   virtual const char* kernel_name() const = 0;

@@ -234,7 +234,7 @@ template <typename real>
 struct Env1D : bcn_env_s {
   Env1DArgs<real> a{};
   int nfields = 4;
-  DevBuf fields, a_last, a_prev, stpbuf;
+  DevBuf fields, a_last, a_prev, stpbuf, nctrbuf;
   const char* kname = "";
 
   int init(int n_actions) {
@@ -254,11 +254,22 @@ struct Env1D : bcn_env_s {
     if ((rc = stpbuf.alloc((size_t)batch * sizeof(int32_t)))) return rc;
     BCN_HIP(hipMemset(stpbuf.p, 0, stpbuf.bytes));
     stp = a.stp = static_cast<int32_t*>(stpbuf.p);
+    if ((rc = nctrbuf.alloc((size_t)batch * sizeof(uint32_t)))) return rc;
+    BCN_HIP(hipMemset(nctrbuf.p, 0, nctrbuf.bytes));
+    a.nctr = static_cast<uint32_t*>(nctrbuf.p);
+    a.nsigma = 0; a.nseed_lo = 0; a.nseed_hi = 0; a.noff = 0;
     return BCN_OK;
   }
   ~Env1D() override {
     DeviceGuard g(device);
-    fields.release(); a_last.release(); a_prev.release(); stpbuf.release();
+    fields.release(); a_last.release(); a_prev.release(); stpbuf.release(); nctrbuf.release();
+  }
+  int set_noise(double sigma, uint64_t seed, int64_t replica_offset) override {
+    if (!(sigma >= 0) || replica_offset < 0) { bcn_set_error("bcn_set_noise: sigma >= 0 and replica_offset >= 0"); return BCN_ERR_ARG; }
+    a.nsigma = (real)sigma; a.nseed_lo = (uint32_t)seed; a.nseed_hi = (uint32_t)(seed >> 32); a.noff = (int)replica_offset;
+    DeviceGuard g(device);
+    BCN_HIP(hipMemset(nctrbuf.p, 0, nctrbuf.bytes));
+    return BCN_OK;
   }
   size_t state_elems() const override { return (size_t)nfields * a.n; }
   int copy_state(void* buf, int is_device, hipStream_t s, bool out) {
@@ -581,6 +592,10 @@ int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream) {
 int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_elems) {
   if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }
   return h->set_fast_plugin(launch_fn, scratch_elems);
+}
+int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t replica_offset) {
+  if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }
+  return h->set_noise(sigma, seed, replica_offset);
 }
 int bcn_set_option(bcn_env_t h, const char* name, int value) {
   if (!h || !name) { bcn_set_error("null handle/name"); return BCN_ERR_ARG; }

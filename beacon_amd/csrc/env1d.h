@@ -27,6 +27,12 @@ struct Env1DArgs {
   // per-call I/O
   const real* actions;
   const real* noise;
+  // inlet noise drawn on the device when `noise` is NULL (bcn_set_noise): uniform(-nsigma, nsigma) from Philox4x32-10 keyed by
+  // the seed, counter = (global replica index, this replica's step counter nctr[b], timestep, 0); nsigma = 0: no noise
+  real nsigma;
+  uint32_t nseed_lo, nseed_hi;
+  int noff;                 // global index of replica 0 (sharded batches)
+  uint32_t* nctr;           // [B] steps taken with device noise (advanced by the kernel: a captured graph replays fresh noise)
   const real* init_fields;
   const uint8_t* mask;      // per-replica enable (NULL = all)
   real* obs_out;
@@ -35,6 +41,29 @@ struct Env1DArgs {
   uint8_t* trunc;
   int32_t* status;
 };
+
+// Philox4x32-10 (Salmon et al., SC'11): four 32-bit words per (counter, key)
+__device__ __forceinline__ void bcn_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                               uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform(-sigma, sigma) of replica b (local index), draw counter ctr, timestep k
+template <typename real>
+__device__ __forceinline__ real bcn_device_noise(const Env1DArgs<real>& A, int b, uint32_t ctr, int k) {
+  uint32_t o[4];
+  bcn_philox4x32((uint32_t)(b + A.noff), ctr, (uint32_t)k, 0u, A.nseed_lo, A.nseed_hi, o);
+  const real r = sizeof(real) == 8 ? (real)((((unsigned long long)o[0] << 21) ^ (unsigned long long)(o[1] >> 11)) & ((1ull << 53) - 1)) *
+                                         (real)(1.0 / 9007199254740992.0)
+                                   : (real)(o[0] >> 8) * (real)(1.0 / 16777216.0);
+  return (real(2) * r - real(1)) * A.nsigma;
+}
 
 template <typename real> int burgers_launch_step(const Env1DArgs<real>& a, int batch, hipStream_t s);
 template <typename real> int burgers_launch_reset(const Env1DArgs<real>& a, int batch, hipStream_t s);

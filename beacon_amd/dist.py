@@ -97,6 +97,8 @@ class ShardedVecEnv(object):
         if getattr(local_env, "gen", None) is not None and (self.sh.world > 1 or seed is not None):
             base = int(getattr(local_env, "seed", 0) if seed is None else seed)
             local_env.gen.manual_seed(base + self.lo)
+            if hasattr(local_env, "set_noise_seed"):       # in-kernel noise: one seed, keyed by the GLOBAL replica index
+                local_env.set_noise_seed(base, self.lo)
 
     def _like_actions(self):
         e = self.env

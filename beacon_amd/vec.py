@@ -174,6 +174,13 @@ class VecEnv(object):
         """Solver options by name (include/beacon_hip.h: bcn_set_option), e.g. ("conv_plan", 0)."""
         _lib.check(self.lib.bcn_set_option(self.h, name.encode(), int(value)))
 
+    def set_noise_seed(self, seed, replica_offset=0):
+        """Envs with inlet noise (burgers, shkadov): step() without an explicit `noise` tensor lets the step kernel draw
+        uniform(-sigma, sigma) itself (include/beacon_hip.h: bcn_set_noise) -- keyed by `seed`, the global replica index
+        `replica_offset + b`, the replica's count of such steps and the timestep."""
+        self.seed, self.replica_offset = int(seed), int(replica_offset)
+        _lib.check(self.lib.bcn_set_noise(self.h, float(self.sigma), self.seed, self.replica_offset))
+
     def get_counters(self):
         """uint64 [B, 4] of the last step, per replica: shader cycles inside the Jacobi loop / in the whole replica, late
         stops of the extrapolating residual plan, repeated timesteps (include/beacon_hip.h: bcn_get_counters)."""
@@ -480,10 +487,10 @@ class VecBurgers(VecEnv):
     def __init__(self, batch, device="cuda:0", dtype="f32", u_target=0.5, amp=10.0, sigma=0.1,
                  ctrl_pos=1.0, L=2.0, nx=500, seed=0):
         self._derive(u_target, amp, sigma, ctrl_pos, L, nx)
+        self.seed, self.replica_offset = int(seed), 0
         super().__init__(batch, device, dtype)
         self.action_space = Box(-1.0, 1.0, (1,))
         self.observation_space = Box(0.0, 1.0, (self.n_obs_pts,))
-        self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(self.seed)
 
@@ -504,12 +511,15 @@ class VecBurgers(VecEnv):
         self.cfg = c
         _lib.check(self.lib.bcn_burgers_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
                                                C.byref(self.h)))
+        self.set_noise_seed(self.seed, self.replica_offset)
 
     def state_shape(self):
         return (3, self.nx)
 
     def draw_noise(self):
-        """Device-side stand-in for np.random.uniform(-sigma, sigma, 1) (burgers.py:127)."""
+        """An explicit noise tensor of the reference's law, np.random.uniform(-sigma, sigma, 1) (burgers.py:127), from the
+        env's torch generator -- for callers that want to see or reuse the draws.  step(a) without `noise` needs none:
+        the kernel draws its own (set_noise_seed)."""
         r = torch.rand((self.batch,), generator=self.gen, device=self.device, dtype=self.tdtype)
         return (2.0 * r - 1.0) * self.sigma
 
@@ -518,7 +528,7 @@ class VecBurgers(VecEnv):
 
     def _step(self, actions, noise=None):
         a = self._real(actions, (self.batch,))
-        nz = self.draw_noise() if noise is None else self._real(noise, (self.batch,))
+        nz = None if noise is None else self._real(noise, (self.batch,))     # None: drawn inside the kernel
         self._keep = (a, nz)
         _lib.check(self.lib.bcn_burgers_step(self.h, _ptr(a), _ptr(nz), _ptr(self.obs), _ptr(self.rwd),
                                              _ptr(self.done), _ptr(self.trunc), _ptr(self.status),
@@ -535,10 +545,10 @@ class VecShkadov(VecEnv):
                  jet_pos=150.0, jet_space=10.0, delta=0.1, t_act=20.0, seed=0):
         self._derive(L0, n_jets, jet_pos, jet_space, delta, t_act)
         self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
+        self.seed, self.replica_offset = int(seed), 0
         super().__init__(batch, device, dtype)
         self.action_space = Box(-1.0, 1.0, (n_jets,))
         self.observation_space = Box(-1.0, 1.0, (self.n_obs * n_jets,))
-        self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(self.seed)
         self._init_dev = None
@@ -574,6 +584,7 @@ class VecShkadov(VecEnv):
         self.cfg = c
         _lib.check(self.lib.bcn_shkadov_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
                                                C.byref(self.h)))
+        self.set_noise_seed(self.seed, self.replica_offset)
 
     def state_shape(self):
         return (4, self.nx)
@@ -601,7 +612,7 @@ class VecShkadov(VecEnv):
 
     def _step(self, actions, noise=None):
         a = self._real(actions, (self.batch, self.n_jets))
-        nz = self.draw_noise() if noise is None else self._real(noise, (self.batch, self.ndt_act))
+        nz = None if noise is None else self._real(noise, (self.batch, self.ndt_act))   # None: drawn inside the kernel
         self._keep = (a, nz)
         _lib.check(self.lib.bcn_shkadov_step(self.h, _ptr(a), _ptr(nz), _ptr(self.obs), _ptr(self.rwd),
                                              _ptr(self.done), _ptr(self.trunc), _ptr(self.status),

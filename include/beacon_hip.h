@@ -187,6 +187,14 @@ BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
  * is passed here together with bcn_jit_scratch_elems().  Selects variant 1; launch_fn = NULL restores the built-in
  * choice.  The plugin must outlive the handle. */
 BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_elems);
+/* Inlet noise on the device (burgers, shkadov).  The reference draws np.random.uniform(-sigma, sigma, 1) from numpy's global
+ * stream -- once per action step (burgers.py:127), once per timestep (shkadov.py:204) -- and the *_step entry points take those
+ * draws as noise_dev, so that a caller can reproduce the reference's stream.  A trainer that only needs noise of that law leaves
+ * noise_dev NULL after this call: the step kernel then draws uniform(-sigma, sigma) itself (Philox4x32-10 keyed by `seed`, counter =
+ * (replica_offset + replica index, the replica's own count of such steps, timestep)) -- no extra launch, no host work, fresh values
+ * when a captured graph replays.  sigma = 0 (the default) restores "NULL = no noise".  replica_offset: global index of this handle's
+ * replica 0 (sharded batches).  Resets the replicas' draw counters.  BCN_ERR_ARG for envs without inlet noise. */
+BCN_API int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t replica_offset);
 /* Solver options of the 2D envs (no reference counterpart), by name:
  *   "conv_plan"   which Jacobi sweeps evaluate the residual sum((phi - phin)^2) of rayleigh.py:448-449 / mixing.py:457-458
  *                 in the register-resident kernels: 0 = every sweep, as the reference does; 1 = every sweep that can pass

@@ -1115,6 +1115,55 @@ def test_burgers_vs_golden(dtype, tol):
     env.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_inlet_noise_drawn_inside_the_step_kernel(dtype):
+    """step() without a noise tensor: the kernel draws uniform(-sigma, sigma) itself (bcn_set_noise: Philox4x32-10 keyed by
+    the seed, the GLOBAL replica index, the replica's step count and the timestep).  burgers keeps its inlet value
+    u[0] = u_target + noise in the state (burgers.py:137), shkadov h[0] = 1 + noise of the last timestep (shkadov.py:204):
+    the law (range, mean, variance), independence across replicas and steps, reproducibility from the seed, the
+    replica offset of a sharded batch, and fresh values when a captured graph replays."""
+    B = 1024
+    def inlet(env):
+        return (env.get_state()[:, 0, 0].double() - env.u_target).cpu().numpy()
+    env = V.VecBurgers(B, DEV, dtype, seed=5)
+    env.reset()
+    zero = torch.zeros(B, dtype=env.tdtype, device=DEV)
+    env.step(zero)
+    n1 = inlet(env)
+    env.step(zero)
+    n2 = inlet(env)
+    s = env.sigma
+    for n in (n1, n2):
+        assert np.abs(n).max() <= s * (1 + 1e-6) and abs(n.mean()) < 4 * s / np.sqrt(3 * B)
+        assert 0.9 * s / np.sqrt(3) < n.std() < 1.1 * s / np.sqrt(3) and len(np.unique(n)) > 0.99 * B
+    assert abs(np.corrcoef(n1, n2)[0, 1]) < 0.15 and abs(np.corrcoef(n1[:-1], n1[1:])[0, 1]) < 0.15
+    env.close()
+    same = V.VecBurgers(B, DEV, dtype, seed=5)
+    same.reset(); same.step(zero)
+    assert np.array_equal(inlet(same), n1)                       # the seed reproduces the stream ...
+    same.set_noise_seed(6); same.reset(); same.step(zero)
+    assert not np.array_equal(inlet(same), n1)                   # ... another seed gives another
+    same.close()
+    half = V.VecBurgers(B // 2, DEV, dtype, seed=5)              # the upper shard of a batch split over two ranks
+    half.set_noise_seed(5, B // 2)
+    half.reset(); half.step(zero[:B // 2])
+    assert np.array_equal(inlet(half), n1[B // 2:])
+    half.close()
+    env = V.VecBurgers(64, DEV, dtype, seed=1)
+    env.reset()
+    g = env.capture(torch.zeros((2, 64), dtype=env.tdtype, device=DEV), None, n_steps=2)
+    g.replay(); a = inlet(env)
+    g.replay(); b = inlet(env)
+    assert not np.array_equal(a, b)                              # the draw counter lives on the device: a replay draws anew
+    env.close()
+    env = V.VecShkadov(256, DEV, dtype, None, n_jets=5, seed=2)
+    env.reset()
+    env.step(torch.zeros((256, 5), dtype=env.tdtype, device=DEV))
+    h0 = (env.get_state()[:, 0, 0].double() - 1.0).cpu().numpy()
+    assert np.abs(h0).max() <= env.sigma * (1 + 1e-6) and h0.std() > 0.4 * env.sigma and len(np.unique(h0)) > 250
+    env.close()
+
+
 def test_burgers_nx512_vs_oracle_and_mirror():
     """BASELINE grid N=512 (the reference hard-codes 500) against the oracle; plus the
     reference-style class drawing its noise from numpy's global stream."""
