@@ -313,6 +313,8 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
                      "extrapolating plan without the late-stop guard (round 2's default)")
     # rayleigh 128x64 float64 (the reference's arithmetic), B=512, the headline's own steps
     headline_variant("headline workload (rayleigh-v0 128x64 B=512) in float64", "f64", {}, "the reference's arithmetic; proven plan (conv_plan 1)")
+    headline_variant("headline workload in float64, conv_plan=3", "f64", {"conv_plan": 3},
+                     "the float32 default's stop rule (extrapolated, late stops repeated under the proven plan) in the reference's arithmetic")
     # mixing 100x100 B=512 (configs[4])
     env = V.VecMixing(512, dev, "f32")
     env.reset()
