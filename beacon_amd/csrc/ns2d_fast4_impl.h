@@ -1,0 +1,592 @@
+// ns2d_fast4_impl.h -- rayleigh / mixing action step for TALL grids (128 < ny <= 256): Jacobi sweeps in registers with
+// RPL = 2..4 rows per lane, the other phases from HBM/L2 with lanes along x, the ordered transport as a register walk
+// along anti-diagonals fed from LDS.
+//
+// Why not "everything in registers" like ns2d_fast_impl.h / ns2d_fast2_impl.h: 100x200 cells x 6 live fields x 4 B is
+// 480 KB, the whole vector register file of a CU (512 KB).  What does fit is the Poisson solve -- phi, phi' and the rhs
+// (3 x 80 KB at 100x200 float32) -- and that is where the sweeps are (rayleigh.py:419-454 / mixing.py:428-463).  So:
+//
+//  * u, v, p, S, us, vs stay in HBM/L2 ([ny+2][nx+2], x fastest): boundary conditions, predictor, p += phi, corrector
+//    and the explicit part of the transport run over them with lanes along x (coalesced), as in ns2d_generic.hip.
+//  * Poisson: wave w owns the column strip [w R + 1, w R + R], lane l the rows [l RPL + 1, (l+1) RPL]: the vertical
+//    neighbours of a cell are in the lane's own registers except across lanes (one DPP move up, one down per COLUMN),
+//    the horizontal ones in the wave's own registers except at the strip edges, which go through LDS once per sweep
+//    (RPL contiguous values per lane).  The residual of the reference's stop test (sum over the whole array incl.
+//    ghosts, rayleigh.py:448-449) is evaluated after EVERY sweep, as the reference does; its workgroup reduction shares
+//    the one barrier per sweep with the edge exchange.  16 waves of <= 128 VGPRs: four per SIMD hide each other's
+//    DPP / LDS latencies.
+//  * the reference's IN-PLACE transport sweep (rayleigh.py:468-487): S' = A + aW S'(i-1,j) + aS S'(i,j-1).  A, aW, aS are
+//    computed by all waves into LDS (as many rows at a time as fit: two blocks at 100x200 float32); then ONE wave walks
+//    the anti-diagonals d = i + j with lanes along x: the west value is the neighbouring lane's previous result (one
+//    DPP move), the south value the lane's own previous result -- two dependent FMAs per diagonal, no barrier and no
+//    memory round trip inside the chain; the coefficients of the next diagonal are fetched from LDS (odd pitch: no bank
+//    conflicts along a diagonal) while the current one is computed.
+//
+// Same argument block, state layout, status / sweep-count outputs and episode bookkeeping as the other kernels.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "bcn_dpp.h"
+#include "ns2d.h"
+#include "ns2d_device.h"
+#include "ns2d_sched.h"
+
+namespace {
+
+using namespace bcn_dpp;
+
+template <int NX, int NY, int R, int RPL>
+struct Fast4Geom {
+  static constexpr int SX = NX + 2;
+  static constexpr int NCELL = SX * (NY + 2);
+  static constexpr int NW = (NX + R - 1) / R;       // waves = column strips
+  static constexpr int RL = NX - (NW - 1) * R;      // columns of the last strip (1..R)
+  static constexpr int NT = NW * BCN_WAVE;
+  static constexpr int NL = NY / RPL;               // lanes that hold rows
+  static constexpr int P = SX | 1;                  // LDS pitch of a natural-layout array (odd)
+  static constexpr int CPL = (NX + BCN_WAVE - 1) / BCN_WAVE;  // columns per lane of the transport walk
+  static constexpr int HROWS = BCN_WAVE * RPL;      // one edge column in the exchange buffer (lane-major)
+  static constexpr int FIXED = 2 * 32 + 64;         // reduction scratch [2][2][16] + conditioned actions
+  static constexpr int HAL = 2 * NW * 2 * HROWS;    // [parity][wave][west|east][HROWS]
+  static constexpr int WARR = P * (NY + 2);
+  static constexpr int LDS_ELEMS_MAX(int esz) { return 160 * 1024 / esz; }
+  // transport: rows per block and number of blocks
+  static constexpr int br_cap(int esz) { return (LDS_ELEMS_MAX(esz) - FIXED) / (3 * P); }
+  static constexpr int nblk(int esz) { return (NY + br_cap(esz) - 1) / br_cap(esz); }
+  static constexpr int br(int esz) { return (NY + nblk(esz) - 1) / nblk(esz); }
+  static constexpr int lds_elems(int esz) {
+    const int jac = FIXED + HAL + WARR, tr = FIXED + 3 * P * br(esz);
+    return jac > tr ? jac : tr;
+  }
+  static_assert(NY % RPL == 0 && NL <= BCN_WAVE, "rows per lane must divide ny");
+  static_assert(NW >= 2 && NW <= 16 && RL >= 1, "2..16 column strips");
+};
+
+// Cells (i, j), j_lo <= j <= j_hi, with lanes along x and the rows dealt round-robin to the waves, U rows (U * CPL cells) of
+// a lane at a time: ld(j, i) reads what a cell needs (clamped indices: always in range), st(values, j, i, ok) computes and
+// writes.  All loads of the U * CPL cells are issued before the first store: the fields of 256 replicas do not fit L2, a
+// load costs more than a microsecond, and one cell at a time (the loop of ns2d_generic.hip) pays that once per cell.
+template <int NX, int NW, int U, class LD, class ST>
+__device__ __forceinline__ void f4_cells(int w, int tx, int j_lo, int j_hi, LD&& ld, ST&& st) {
+  constexpr int CPL = (NX + BCN_WAVE - 1) / BCN_WAVE;
+  for (int jb = j_lo + w; jb <= j_hi; jb += NW * U) {
+    decltype(ld(0, 0)) vals[U][CPL];
+#pragma unroll
+    for (int uu = 0; uu < U; uu++)
+#pragma unroll
+      for (int a = 0; a < CPL; a++) {
+        const int j = jb + uu * NW, i = 1 + tx + BCN_WAVE * a;
+        vals[uu][a] = ld(j <= j_hi ? j : j_hi, i <= NX ? i : NX);
+      }
+#pragma unroll
+    for (int uu = 0; uu < U; uu++)
+#pragma unroll
+      for (int a = 0; a < CPL; a++) {
+        const int j = jb + uu * NW, i = 1 + tx + BCN_WAVE * a;
+        const bool ok = (j <= j_hi) && (i <= NX);
+        st(vals[uu][a], j <= j_hi ? j : j_hi, i <= NX ? i : NX, ok);
+      }
+  }
+}
+
+template <typename real> struct F4Pred { real u[6], v[6], p[3], s; };
+template <typename real> struct F4Rhs { real u0, u1, v0, v1; };
+template <typename real> struct F4Corr { real p, us, vs, gx, gy; };
+template <typename real> struct F4Tr { real uW, uE, vS, vN, Tc, TE, TN, TW; };
+
+template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
+__global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_step(NS2DArgs<real> A) {
+  using G = Fast4Geom<NX, NY, R, RPL>;
+  constexpr int NW = G::NW, NT = G::NT, SX = G::SX, P = G::P, RL = G::RL, NL = G::NL, CPL = G::CPL, HROWS = G::HROWS;
+  constexpr int BR = G::br(sizeof(real)), NBLK = G::nblk(sizeof(real));
+#ifndef BCN_F4_U
+#define BCN_F4_U 2
+#endif
+  constexpr int U = (CPL >= BCN_F4_U) ? 1 : BCN_F4_U / CPL;   // rows of a lane in flight in the HBM/L2 phases
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
+  const int tid = threadIdx.x;
+  const int tx = tid & (BCN_WAVE - 1), w = tid >> 6;
+  const size_t off = (size_t)b * G::NCELL;
+
+  real* red = reinterpret_cast<real*>(smem);  // [2][2][16]
+  real* sact = red + 2 * 32;                  // [64] conditioned actions
+  real* hal = sact + 64;                      // Poisson: edge-column exchange
+  real* W = hal + G::HAL;                     // Poisson: -rhs in, phi out (natural layout, pitch P)
+  real* TX = sact + 64;                       // transport (overlays the two above): A -> S', aW, aS of one row block
+  real* TY = TX + BR * P;
+  real* TZ = TY + BR * P;
+
+  real* __restrict__ u = A.u + off;
+  real* __restrict__ v = A.v + off;
+  real* __restrict__ p = A.p + off;
+  real* __restrict__ S = A.S + off;
+  real* __restrict__ us = A.us + off;
+  real* __restrict__ vs = A.vs + off;
+
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long t_jac = 0, n_eval = 0, n_late = 0, n_redo = 0;
+#ifdef BCN_F4_STAMP   // experiments: shader cycles per phase; replica b reports phase b % 8 in its third counter
+  unsigned long long t_ph = 0, t_last = t_begin;
+#define BCN_F4_PH(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((b & 7) == (k)) t_ph += t_ - t_last; t_last = t_; }
+#else
+#define BCN_F4_PH(k)
+#endif
+
+  if (tid < 2 * 32) red[tid] = 0;
+  // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----
+  real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
+  if constexpr (KIND == 0) {
+    const int n = A.n_sgts;
+    const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
+    real mean = 0;
+    for (int k = 0; k < n; k++) mean += src[k];
+    mean /= (real)n;
+    real m = 1;
+    for (int k = 0; k < n; k++) {
+      real t = bcn_abs(src[k] - mean) / A.C;
+      m = t > m ? t : m;
+    }
+    real mine = (tid < n) ? (src[tid] - mean) / m : real(0);
+    __syncthreads();  // all reads of a_last done before it is rewritten
+    if (tid < n) {
+      sact[tid] = mine;
+      A.a_last[(size_t)b * n + tid] = mine;
+      if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
+    }
+  } else {
+    int act = A.iactions ? A.iactions[b] : A.ia_last[b];
+    __syncthreads();
+    if (tid == 0) A.ia_last[b] = act;
+    if (act == 0) { u_b = A.u_max; u_t = -A.u_max; }
+    if (act == 1) { u_b = -A.u_max; u_t = A.u_max; }
+    if (act == 2) { v_r = A.u_max; v_l = -A.u_max; }
+    if (act == 3) { v_r = -A.u_max; v_l = A.u_max; }
+  }
+  __syncthreads();
+
+  // ---- Poisson mapping: wave = column strip, lane = RPL rows ----
+  const bool lastw = (w == NW - 1);
+  const bool rowsl = tx < NL;
+  const int i0 = 1 + w * R, j0l = 1 + tx * RPL;
+  const real cxl = rowsl ? A.cx : real(0), cyl = rowsl ? A.cy : real(0);
+  const real tmask = (KIND == 0 && tx == NL - 1) ? real(1) : real(0);   // Neumann top wall (rayleigh); mixing: phi = 0 above
+  const real bmask = (tx == 0) ? real(1) : real(0);
+  // exchange slots: west edge -> east halo of the strip to the left (own west halo at the wall: Neumann), and vice versa
+  real* const hw_rd0 = hal + (w * 2 + 0) * HROWS + tx * RPL;
+  real* const he_rd0 = hal + (w * 2 + 1) * HROWS + tx * RPL;
+  real* const hw_wr0 = hal + ((w == 0 ? 0 : (w - 1) * 2 + 1)) * HROWS + tx * RPL;
+  real* const he_wr0 = hal + ((lastw ? w * 2 + 1 : (w + 1) * 2 + 0)) * HROWS + tx * RPL;
+  constexpr int HPAR = NW * 2 * HROWS;
+
+  int status = 0;
+  for (int it = 0; it < A.ndt_act && status == 0; it++) {
+    // ---- boundary conditions (rayleigh.py:180-202 / mixing.py:153-171) ----
+    BCN_F4_PH(7)
+    for (int j = 1 + tid; j <= NY; j += NT) {
+      u[j * SX + 1] = 0;
+      u[j * SX + NX + 1] = 0;
+      if (j >= 2) {
+        v[j * SX + 0] = 2 * v_l - v[j * SX + 1];
+        v[j * SX + NX + 1] = 2 * v_r - v[j * SX + NX];
+      }
+      S[j * SX + 0] = S[j * SX + 1];
+      S[j * SX + NX + 1] = S[j * SX + NX];
+    }
+    for (int i = 1 + tid; i <= NX + 1; i += NT) {
+      // u[1,.] and u[nx+1,.] are zeroed by the loop above in the same phase: use the value they will have
+      const bool wall = (i == 1) || (i == NX + 1);
+      real utop = wall ? real(0) : u[NY * SX + i];
+      real ubot = wall ? real(0) : u[1 * SX + i];
+      u[(NY + 1) * SX + i] = 2 * u_t - utop;
+      u[0 * SX + i] = 2 * u_b - ubot;
+      if (i <= NX) {
+        v[(NY + 1) * SX + i] = 0;
+        v[1 * SX + i] = 0;
+        if constexpr (KIND == 0) {
+          S[(NY + 1) * SX + i] = 2 * A.Tc - S[NY * SX + i];
+          int k = (i - 1) / A.nx_sgts;
+          if (k < A.n_sgts) S[0 * SX + i] = 2 * (A.Th + sact[k]) - S[1 * SX + i];
+        } else {
+          S[(NY + 1) * SX + i] = S[NY * SX + i];
+          S[0 * SX + i] = S[1 * SX + i];
+        }
+      }
+    }
+    __syncthreads();
+    BCN_F4_PH(0)
+
+    // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) ----
+    f4_cells<NX, NW, U>(w, tx, 1, NY,
+      [&](int j, int i) {
+        const int c = j * SX + i;
+        F4Pred<real> q;
+        q.u[0] = u[c]; q.u[1] = u[c + 1]; q.u[2] = u[c - 1]; q.u[3] = u[c + SX]; q.u[4] = u[c - SX]; q.u[5] = u[c + 1 - SX];
+        q.v[0] = v[c]; q.v[1] = v[c + 1]; q.v[2] = v[c - 1]; q.v[3] = v[c + SX]; q.v[4] = v[c - SX]; q.v[5] = v[c + SX - 1];
+        q.p[0] = p[c]; q.p[1] = p[c - 1]; q.p[2] = p[c - SX];
+        q.s = (KIND == 0) ? S[c] : real(0);
+        return q;
+      },
+      [&](const F4Pred<real>& q, int j, int i, bool ok) {
+        const int c = j * SX + i;
+        const real uc = q.u[0], uE_ = q.u[1], uW_ = q.u[2], uN_ = q.u[3], uS_ = q.u[4];
+        const real vc = q.v[0], vE_ = q.v[1], vW_ = q.v[2], vN_ = q.v[3], vS_ = q.v[4];
+        const real pc = q.p[0];
+        if (ok && i >= 2) {
+          real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+          real uN = real(0.5) * (uN_ + uc), uS = real(0.5) * (uc + uS_);
+          real vN = real(0.5) * (vN_ + q.v[5]), vS = real(0.5) * (vc + vW_);
+          real conv = (uE * uE - uW * uW) * A.rdx + (uN * vN - uS * vS) * A.rdy;
+          real diff = ((uE_ - 2 * uc + uW_) * A.rdx2 + (uN_ - 2 * uc + uS_) * A.rdy2) * A.kmom;
+          real pres = (pc - q.p[1]) * A.rdx;
+          us[c] = uc + A.dt * (diff - conv - pres);
+        }
+        if (ok && j >= 2) {
+          real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+          real uE = real(0.5) * (uE_ + q.u[5]), uW = real(0.5) * (uc + uS_);
+          real vN = real(0.5) * (vN_ + vc), vS = real(0.5) * (vc + vS_);
+          real conv = (uE * vE - uW * vW) * A.rdx + (vN * vN - vS * vS) * A.rdy;
+          real diff = ((vE_ - 2 * vc + vW_) * A.rdx2 + (vN_ - 2 * vc + vS_) * A.rdy2) * A.kmom;
+          real pres = (pc - q.p[2]) * A.rdy;
+          vs[c] = vc + A.dt * (diff - conv - pres + q.s);
+        }
+      });
+    __syncthreads();
+    BCN_F4_PH(1)
+
+    // ---- Poisson rhs (rayleigh.py:424-426), negated, into LDS with lanes along x ----
+    f4_cells<NX, NW, 2 * U>(w, tx, 1, NY,
+      [&](int j, int i) {
+        const int c = j * SX + i;
+        return F4Rhs<real>{us[c], us[c + 1], vs[c], vs[c + SX]};
+      },
+      [&](const F4Rhs<real>& q, int j, int i, bool ok) {
+        if (ok) W[j * P + i] = -(A.cb * ((q.u1 - q.u0) * A.rdx + (q.v1 - q.v0) * A.rdy));
+      });
+    __syncthreads();
+
+    // ---- Jacobi sweeps in registers (rayleigh.py:419-454 / mixing.py:428-463) ----
+    const unsigned long long tj0 = __builtin_amdgcn_s_memtime();
+    real Pv[R][RPL], Bv[R][RPL];
+#pragma unroll
+    for (int k = 0; k < R; k++)
+#pragma unroll
+      for (int r = 0; r < RPL; r++) {
+        const bool ok = rowsl && (k < RL || !lastw);
+        Bv[k][r] = ok ? W[(j0l + r) * P + i0 + k] : real(0);
+      }
+    int itp = 0, par = 0;
+    real err = 0, eU = 0;
+    // One sweep, in place (a column is overwritten once its west neighbour no longer needs the old values).  EV: with the
+    // residual of the reference's stop test (weighted: ghosts copy their interior neighbour, one more count per Neumann side)
+    // and the plain sum of squares the evaluation plan works with; their workgroup reduction shares the barrier of the
+    // edge exchange.
+    // (a macro, not a lambda: with the register arrays captured by reference hipcc turned `lastw ? Pv[RL - 1][r] : Pv[R - 1][r]`
+    //  into a run-time index and moved the array to scratch memory)
+#ifdef BCN_F4_NOBAR   // timing experiments only (wrong results)
+#define BCN_F4_BAR(EV) if (EV) __syncthreads();
+#else
+#define BCN_F4_BAR(EV) __syncthreads();
+#endif
+#define BCN_F4_SWEEP(EV) {                                                                                                         \
+      real west[RPL], east[RPL], acc[RPL], accW = 0, accE = 0;                                                                     \
+      _Pragma("unroll")                                                                                                            \
+      for (int r = 0; r < RPL; r++) {                                                                                              \
+        west[r] = hw_rd0[par * HPAR + r];                                                                                          \
+        east[r] = he_rd0[par * HPAR + r];                                                                                          \
+        acc[r] = 0;                                                                                                                \
+      }                                                                                                                            \
+      _Pragma("unroll")                                                                                                            \
+      for (int k = 0; k < R; k++) {                                                                                                \
+        if (k < RL || !lastw) {                                                                                                    \
+          real cur[RPL];                                                                                                           \
+      _Pragma("unroll")                                                                                                            \
+          for (int r = 0; r < RPL; r++) cur[r] = Pv[k][r];                                                                         \
+          const real sdn = from_below<real>(cur[0], cur[RPL - 1]);                                                                 \
+          real nup = dpp<0x130, 0xf, 0xf, true>(real(0), cur[0]);                                                                  \
+          if constexpr (KIND == 0) nup = tmask * cur[RPL - 1] + nup;                                                               \
+      _Pragma("unroll")                                                                                                            \
+          for (int r = 0; r < RPL; r++) {                                                                                          \
+            const real s = (r == 0) ? sdn : cur[r - 1];                                                                            \
+            const real n = (r == RPL - 1) ? nup : cur[r + 1];                                                                      \
+            real e;                                                                                                                \
+            if (k == R - 1) e = east[r];                                                                                           \
+            else if (k == RL - 1) e = lastw ? east[r] : Pv[k + 1 < R ? k + 1 : k][r];                                              \
+            else e = Pv[k + 1 < R ? k + 1 : k][r];                                                                                 \
+            const real wv = west[r];                                                                                               \
+            real ph;                                                                                                               \
+            if constexpr (EQ) ph = cxl * ((e + wv) + (n + s)) + Bv[k][r];                                                          \
+            else ph = cyl * (n + s) + (cxl * (e + wv) + Bv[k][r]);                                                                 \
+            if (EV) {                                                                                                              \
+              const real d = ph - cur[r];                                                                                          \
+              acc[r] += d * d;                                                                                                     \
+              if (k == 0) accW += d * d;                                                                                           \
+              if (k == RL - 1) accE += d * d;                                                                                      \
+            }                                                                                                                      \
+            Pv[k][r] = ph;                                                                                                         \
+            west[r] = cur[r];                                                                                                      \
+          }                                                                                                                        \
+        }                                                                                                                          \
+      }                                                                                                                            \
+      const int np = par ^ 1;                                                                                                      \
+      _Pragma("unroll")                                                                                                            \
+      for (int r = 0; r < RPL; r++) {                                                                                              \
+        hw_wr0[np * HPAR + r] = Pv[0][r];                                                                                          \
+        he_wr0[np * HPAR + r] = lastw ? Pv[RL - 1][r] : Pv[R - 1][r];                                                              \
+      }                                                                                                                            \
+      if (EV) {                                                                                                                    \
+        real plain = 0;                                                                                                            \
+      _Pragma("unroll")                                                                                                            \
+        for (int r = 0; r < RPL; r++) plain += acc[r];                                                                             \
+        real loc = plain + bmask * acc[0];                                                                                         \
+        if constexpr (KIND == 0) loc += tmask * acc[RPL - 1];                                                                      \
+        if (w == 0) loc += accW;                                                                                                   \
+        if (lastw) loc += accE;                                                                                                    \
+        loc = wave_sum_lane63<real>(loc);                                                                                          \
+        plain = wave_sum_lane63<real>(plain);                                                                                      \
+        if (tx == BCN_WAVE - 1) { red[np * 32 + w] = loc; red[np * 32 + 16 + w] = plain; }                                         \
+      }                                                                                                                            \
+      BCN_F4_BAR(EV)                                                                                                                \
+      par = np;                                                                                                                    \
+      itp++;                                                                                                                       \
+      if (EV) {                                                                                                                    \
+        const real eW_ = red[np * 32 + (tx & 15)], eU_ = red[np * 32 + 16 + (tx & 15)];                                            \
+        err = read_lane(row16_sum<real>(eW_), 15);                                                                                 \
+        eU = read_lane(row16_sum<real>(eU_), 15);                                                                                  \
+      }                                                                                                                            \
+    }
+    // Which sweeps evaluate the residual (conv_plan 0: all, as the reference) -- the plans of ns2d_fast2_impl.h:
+    //  1 (proven): the increments obey d(k+1) = J d(k) with J symmetric, so log |d(k)|^2 (plain sum of squares) is convex in
+    //    k and never increases: the slope between two evaluations bounds every later slope, and the weighted sum of the stop
+    //    test is >= the plain one.  While that bound stays above 1.02 tol (the margin covers the rounding of the sums) no
+    //    sweep can pass the test: those sweeps run without residual, reduction and test.
+    //  2: the same extrapolation on the weighted sum itself (not proven convex; it is when the residual hovers within the
+    //    weights' 10 % of tol for a hundred sweeps, where plan 1 cannot skip anything), one sweep and 1/16 short of the estimate.
+    //  3 (float32 default): plan 2, guarded: a passing evaluation that directly follows skipped sweeps is a stop the plan did
+    //    not foresee ("late stop": counted) -- the solve starts from phi = 0 and its rhs is still in registers, so it is simply
+    //    repeated under plan 1.
+    int plan = A.conv_plan;
+    for (;;) {
+#pragma unroll
+      for (int k = 0; k < R; k++)
+#pragma unroll
+        for (int r = 0; r < RPL; r++) Pv[k][r] = 0;
+      for (int k = tid; k < G::HAL; k += NT) hal[k] = 0;   // both parities of the exchange buffer start from phi = 0
+      __syncthreads();
+      itp = 0; par = 0;
+      const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+      int k_prev = -1, skip_left = 0;
+      float l2u_prev = 0, l2w_prev = 0;
+      constexpr int JMAX = 256;
+      for (;;) {
+        BCN_F4_SWEEP(true)
+        n_eval++;
+        if (!(err > A.tol)) {
+          if (skip_left > 0) status |= BCN_ST_PLAN;
+          break;
+        }
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
+        int n = 0;
+        if (skip_left > 0) {
+          skip_left--;
+        } else if (plan > 0) {
+          const float l2u = __log2f((float)eU), l2w = __log2f((float)err);
+          int j = 0;
+          if (k_prev >= 0) {
+            const float rg = 1.f / (float)(itp - 1 - k_prev);
+            if (plan == 1) {
+              const float room = l2u - l2tol_u, rho = (l2u - l2u_prev) * rg;
+              if (room > 0.f) j = (rho < 0.f) ? (int)fminf(room / -rho, (float)JMAX) : JMAX;
+            } else {
+              const float room = l2w - l2tol_w, rho = (l2w - l2w_prev) * rg;
+              int jw = 0;
+              if (room > 0.f) jw = (rho < 0.f) ? (int)fminf(room / -rho, (float)JMAX) : JMAX;
+              j = jw - 1 - (jw >> 4) + A.plan_overshoot;
+              j = j > 0 ? j : 0;
+            }
+          }
+          j = __builtin_amdgcn_readfirstlane(j);
+          l2u_prev = l2u; l2w_prev = l2w;
+          k_prev = itp - 1;
+          if (A.verify_conv) skip_left = j; else n = j;
+        }
+        if (n > A.itmax - itp) n = A.itmax - itp > 0 ? A.itmax - itp : 0;   // the overflow test sits in the evaluated sweeps
+        BCN_F4_PH(3)
+        for (; n > 0; n--) BCN_F4_SWEEP(false)
+        BCN_F4_PH(2)   // (stamps: phase 2 = the sweeps without residual, phase 3 = the evaluated ones)
+      }
+      const bool late = plan >= 2 && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
+      if (late) n_late++;
+      if (!(late && A.conv_plan == 3)) break;
+      plan = 1;
+      n_redo++;
+    }
+#undef BCN_F4_SWEEP
+    t_jac += __builtin_amdgcn_s_memtime() - tj0;
+    BCN_F4_PH(3)
+    if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
+
+    // phi -> LDS (natural layout): the corrector runs with lanes along x
+#pragma unroll
+    for (int k = 0; k < R; k++)
+#pragma unroll
+      for (int r = 0; r < RPL; r++)
+        if (rowsl && (k < RL || !lastw)) W[(j0l + r) * P + i0 + k] = Pv[k][r];
+    __syncthreads();
+
+    // ---- p += phi incl. ghosts (rayleigh.py:219), corrector (rayleigh.py:460-464) ----
+    f4_cells<NX, NW, U>(w, tx, 1, NY,
+      [&](int j, int i) {
+        const int c = j * SX + i;
+        // the ghost cells next to an edge cell take the same increment (an interior cell re-reads itself: no extra traffic)
+        const int cgx = (i == 1) ? c - 1 : (i == NX) ? c + 1 : c;
+        const int cgy = (j == 1) ? c - SX : (j == NY && KIND == 0) ? c + SX : c;
+        return F4Corr<real>{p[c], us[c], vs[c], p[cgx], p[cgy]};
+      },
+      [&](const F4Corr<real>& q, int j, int i, bool ok) {
+        if (!ok) return;
+        const int c = j * SX + i;
+        const real ph = W[j * P + i];
+        p[c] = q.p + ph;
+        if (i == 1) p[c - 1] = q.gx + ph;
+        if (i == NX) p[c + 1] = q.gx + ph;
+        if (j == 1) p[c - SX] = q.gy + ph;
+        if (j == NY && KIND == 0) p[c + SX] = q.gy + ph;
+        if (i >= 2) u[c] = q.us - A.dt * (ph - W[j * P + i - 1]) * A.rdx;
+        if (j >= 2) v[c] = q.vs - A.dt * (ph - W[(j - 1) * P + i]) * A.rdy;
+      });
+    __syncthreads();
+    BCN_F4_PH(4)
+
+    // ---- transport (rayleigh.py:468-487), one block of rows at a time ----
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK; blk++) {
+      const int jb0 = 1 + blk * BR;
+      const int jb1 = (jb0 + BR - 1 < NY) ? jb0 + BR - 1 : NY;
+      // explicit part and the two in-place coefficients, lanes along x
+      f4_cells<NX, NW, U>(w, tx, jb0, jb1,
+        [&](int j, int i) {
+          const int c = j * SX + i;
+          return F4Tr<real>{u[c], u[c + 1], v[c], v[c + SX], S[c], S[c + 1], S[c + SX], S[c - 1]};
+        },
+        [&](const F4Tr<real>& q, int j, int i, bool ok) {
+          const real uE = q.uE, uW = q.uW, vN = q.vN, vS = q.vS;
+          const real Tc_ = q.Tc, TE = q.TE, TN = q.TN;
+          real expl = A.ksc * ((TE - 2 * Tc_) * A.rdx2 + (TN - 2 * Tc_) * A.rdy2) -
+                      (uE * real(0.5) * (TE + Tc_) - uW * real(0.5) * Tc_) * A.rdx -
+                      (vN * real(0.5) * (TN + Tc_) - vS * real(0.5) * Tc_) * A.rdy;
+          real aw = A.dt * (A.ksc * A.rdx2 + real(0.5) * uW * A.rdx);
+          real as = A.dt * (A.ksc * A.rdy2 + real(0.5) * vS * A.rdy);
+          real xv = Tc_ + A.dt * expl;
+          if (i == 1) { xv = xv + aw * q.TW; aw = 0; }   // west ghost (old BC value) folded in: same operation order
+          if (ok) {
+            const int t = (j - jb0) * P + i;
+            TX[t] = xv;
+            TY[t] = aw;
+            TZ[t] = as;
+          }
+        });
+      __syncthreads();
+      BCN_F4_PH(5)
+      // ordered part: one wave, lanes along x, walking the anti-diagonals d = i + j of the block
+      if (w == 0) {
+        // lane l: columns i = l CPL + 1 + q; t = j - jb0 of the cell a column has on the current diagonal.  A lone wave issues
+        // an instruction every ~5 cycles, so the walk is branch-free and keeps its indices incrementally: a column that is
+        // outside the block on this diagonal reads and writes the unused cell 0 of the arrays (column 0 of the first row) and
+        // keeps its value; the coefficients are fetched two diagonals ahead of their use.
+        const int len = jb1 - jb0;
+        real x[CPL], a_c[CPL], y_c[CPL], z_c[CPL], a_n[CPL], y_n[CPL], z_n[CPL];
+        int t[CPL], idx[CPL], sel_c[CPL], sel_n[CPL];
+        bool ok_c[CPL], ok_n[CPL];
+        auto fetch = [&](real* a_, real* y_, real* z_, int* sel_, bool* ok_) {
+#pragma unroll
+          for (int q = 0; q < CPL; q++) {
+            ok_[q] = (unsigned)t[q] <= (unsigned)len;
+            sel_[q] = ok_[q] ? idx[q] : 0;
+            a_[q] = TX[sel_[q]]; y_[q] = TY[sel_[q]]; z_[q] = TZ[sel_[q]];
+            t[q] += 1;
+            idx[q] += P;
+          }
+        };
+#pragma unroll
+        for (int q = 0; q < CPL; q++) {
+          const int i = tx * CPL + 1 + q;
+          x[q] = (i <= NX) ? S[(jb0 - 1) * SX + i] : real(0);   // row below the block: the south ghost or the rows done before
+          t[q] = (i <= NX) ? 1 - i : -(1 << 20);
+          idx[q] = t[q] * P + i;
+        }
+        fetch(a_c, y_c, z_c, sel_c, ok_c);
+        fetch(a_n, y_n, z_n, sel_n, ok_n);
+        auto advance = [&](real* a_, real* y_, real* z_, int* sel_, bool* ok_) {
+          // one diagonal with the coefficients in (a_, y_, z_), which are then refilled for the diagonal after the next
+          const real wl = dpp<0x138, 0xf, 0xf, true>(real(0), x[CPL - 1]);   // last column of the lane to the left
+          real xn[CPL];
+          int sel_s[CPL];
+#pragma unroll
+          for (int q = 0; q < CPL; q++) {
+            const real wv = (q == 0) ? wl : x[q - 1];
+            xn[q] = z_[q] * x[q] + (y_[q] * wv + a_[q]);
+            sel_s[q] = sel_[q];
+          }
+#pragma unroll
+          for (int q = 0; q < CPL; q++) x[q] = ok_[q] ? xn[q] : x[q];
+          fetch(a_, y_, z_, sel_, ok_);
+#pragma unroll
+          for (int q = 0; q < CPL; q++) TX[sel_s[q]] = xn[q];
+        };
+        const int nsteps = len + NX;
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st += 2) {
+          advance(a_c, y_c, z_c, sel_c, ok_c);
+          advance(a_n, y_n, z_n, sel_n, ok_n);   // (an odd count runs one diagonal past the block: no column is inside it)
+        }
+      }
+      __syncthreads();
+      BCN_F4_PH(6)
+      for (int j = jb0 + w; j <= jb1; j += NW)
+        for (int i = 1 + tx; i <= NX; i += BCN_WAVE) S[j * SX + i] = TX[(j - jb0) * P + i];
+      __syncthreads();
+    }
+  }
+
+  if (A.cyc && tid == 0) {
+    A.cyc[(size_t)b * 4 + 0] = t_jac;
+    A.cyc[(size_t)b * 4 + 1] = __builtin_amdgcn_s_memtime() - t_begin;
+#ifdef BCN_F4_STAMP
+    A.cyc[(size_t)b * 4 + 2] = t_ph;
+    A.cyc[(size_t)b * 4 + 3] = n_eval;
+#else
+    A.cyc[(size_t)b * 4 + 2] = n_late;   // stops the extrapolating plan did not foresee
+    A.cyc[(size_t)b * 4 + 3] = n_redo;   // solves repeated under the proven plan (conv_plan 3)
+#endif
+  }
+  ns2d_finish<real, NT>(A, b, u, v, S, status, red);
+}
+
+template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
+int launch_fast4_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  using G = Fast4Geom<NX, NY, R, RPL>;
+  const size_t lds = (size_t)G::lds_elems(sizeof(real)) * sizeof(real);
+  NS2DArgs<real> c = a;
+  if (!c.sweeps) c.sweeps = c.sweeps_int;
+  if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
+  auto k = ns2d_fast4_step<real, NX, NY, R, RPL, KIND, EQ>;
+  static unsigned long long set = 0;
+  if (ns2d_first_on_device(set)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
+  BCN_HIP(hipGetLastError());
+  if (a.launched) *a.launched = "ns2d_fast4_step";
+  return BCN_OK;
+}
+
+template <typename real, int NX, int NY, int R, int RPL, int KIND>
+int launch_fast4(const NS2DArgs<real>& a, int batch, hipStream_t s) {
+  // dx == dy (every reference configuration): one multiply per cell instead of two
+  if (a.cx == a.cy) return launch_fast4_eq<real, NX, NY, R, RPL, KIND, true>(a, batch, s);
+  return launch_fast4_eq<real, NX, NY, R, RPL, KIND, false>(a, batch, s);
+}
+
+}  // namespace

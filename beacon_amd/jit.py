@@ -2,11 +2,12 @@
 
 The reference takes any domain size (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: nx = 100 L, ny = 100 H);
 the register-resident kernels are templates over the grid (csrc/ns2d_fast_impl.h: one row per lane, ny <= 64;
-csrc/ns2d_fast2_impl.h: two rows per lane, 64 < ny <= 128, float32).  libbeacon_hip.so carries the metric grid and the
+csrc/ns2d_fast2_impl.h: two rows per lane, 64 < ny <= 128; csrc/ns2d_fast4_impl.h: 128 < ny <= 256, the Poisson solve
+in registers with 2..4 rows per lane and the other phases from HBM/L2).  libbeacon_hip.so carries the metric grid and the
 reference's defaults; for any other grid `plugin_for()` compiles csrc/jit/ns2d_jit.hip for that ONE grid with hipcc
 (about 30 s, once: the shared object is cached in beacon_amd/_jit/, keyed by a hash of its sources and flags, and
 travels with the tree like the library itself) and hands its launcher to the library through bcn_set_fast_plugin.
-No hipcc, BEACON_JIT=0 or a grid the mapping cannot hold (ny > 128, float64 above ny = 64, LDS) -> None: the env keeps the
+No hipcc, BEACON_JIT=0 or a grid the mapping cannot hold (ny > 256, LDS, registers) -> None: the env keeps the
 generic kernel (still on the GPU; only slower)."""
 import ctypes as C
 import fcntl
@@ -70,6 +71,28 @@ def choose(nx, ny, f64, kind):
             lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
             if lds <= LDS_BYTES:
                 return {"rows": 2, "R": r, "gf": 1 if f64 else 0, "nw": nw}
+        return None
+    if ny <= 256:
+        # ns2d_fast4_impl.h: only the Poisson solve lives in registers (rpl rows per lane, strips of r columns); 16 waves of
+        # 128 VGPRs where phi, phi' and the rhs of a strip fit them, else 8 waves of 256
+        rpl = next((q for q in (2, 3, 4) if ny % q == 0 and ny // q <= 64), None)
+        if rpl is None:
+            return None
+        for nwmax, words in ((16, 28), (8, 60)):
+            if (f64 and nwmax > 8) or nwmax > int(os.environ.get("BEACON_JIT_F4_NWMAX", "16")):   # (the variable: experiments)
+                continue
+            r = -(-nx // nwmax)
+            nw = -(-nx // r)
+            if nw < 2 or r * rpl * (2 if f64 else 1) > words:
+                continue
+            pitch = (nx + 2) | 1
+            cap = (LDS_BYTES // esz - 128) // (3 * pitch)
+            if cap < 1:
+                continue
+            nblk = -(-ny // cap)
+            lds = (128 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk))) * esz
+            if lds <= LDS_BYTES:
+                return {"rows": 4, "R": r, "gf": 0, "nw": nw, "rpl": rpl}
     return None
 
 
@@ -91,8 +114,12 @@ def build_plugin(nx, ny, f64, kind, verbose=False):
         return None
     defs = {"BCN_JIT_ROWS": m["rows"], "BCN_JIT_REAL": "double" if f64 else "float", "BCN_JIT_NX": nx, "BCN_JIT_NY": ny,
             "BCN_JIT_R": m["R"], "BCN_JIT_KIND": kind, "BCN_JIT_GF": int(os.environ.get("BEACON_JIT_GF", m["gf"]))}
+    if m["rows"] == 4:
+        defs["BCN_JIT_RPL"] = m["rpl"]
     if os.environ.get("BEACON_JIT_WPE"):              # experiment: waves per SIMD the register allocation must allow
         defs["BCN_JIT_WPE"] = int(os.environ["BEACON_JIT_WPE"])
+    for d in os.environ.get("BEACON_JIT_DEFS", "").split():   # experiments: extra -D flags (scripts/tall_base.py)
+        defs[d.partition("=")[0]] = d.partition("=")[2] or "1"
     name = "ns2d_%dx%d_%s_k%d_r%d_%s.so" % (nx, ny, "f64" if f64 else "f32", kind, m["R"], _signature(defs))
     path = os.path.join(JIT_DIR, name)
     if os.path.exists(path):
@@ -160,7 +187,8 @@ def plugin_for(nx, ny, f64, kind):
 # they ship with the tree; any other grid compiles at its first use
 TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 64, False, 0), (110, 64, True, 0),
               (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
-              (100, 105, False, 1), (50, 70, True, 0)]
+              (100, 105, False, 1), (50, 70, True, 0), (50, 150, False, 0), (50, 150, True, 0), (64, 200, False, 0),
+              (100, 200, False, 1)]
 
 
 def prebuild(grids=None, verbose=False):

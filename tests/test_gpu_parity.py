@@ -719,6 +719,56 @@ def test_conv_plan_3_repeats_late_stops_under_the_proven_plan(kind):
     assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
 
 
+@pytest.mark.parametrize("kind,dtype", [("rayleigh", "f32"), ("rayleigh", "f64"), ("mixing", "f32")])
+def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
+    """ns2d_fast4_impl.h (ny > 128: rayleigh 50x150, mixing 100x200) evaluates the Jacobi residual only where its plan says
+    the stop test can pass.  The plans choose WHICH sweeps are evaluated, never the arithmetic: conv_plan 1 (proven bound),
+    2 (extrapolated), 3 (extrapolated, late stops repeated under 1) must return the sweep counts and fields of conv_plan 0
+    (every sweep, as the reference: rayleigh.py:448-454) bit for bit, with no late stop; verify_conv (every sweep evaluated
+    next to the plan) must flag nothing under the proven plan; and with the test hook plan_overshoot = 12 plan 2 stops late
+    (counted) while plan 3 notices, repeats those solves and still returns the result of conv_plan 0."""
+    def run(plan, over=0, verify=0):
+        if kind == "rayleigh":
+            env = V.VecRayleigh(6, DEV, dtype, None, L=1.0, H=3.0)
+            rng = np.random.default_rng(5)
+            x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+            st0 = np.zeros((4, env.nx + 2, env.ny + 2))
+            st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]
+            env.set_ndt_act(30)
+            env.reset()
+            env.set_state(np.tile(ref_to_dev(st0)[None], (6, 1, 1, 1)))
+            a = rng.uniform(-1, 1, (6, 10))
+        else:
+            env = V.VecMixing(4, DEV, dtype, L=1.0, H=2.0)
+            env.set_ndt_act(30)
+            env.reset()
+            a = np.arange(4)
+        assert env.set_variant(1) == 1
+        env.set_option("conv_plan", plan)
+        env.set_option("plan_overshoot", over)
+        env.set_option("verify_conv", verify)
+        env.step(a)
+        assert env.kernel_name == "ns2d_fast4_step"
+        torch.cuda.synchronize()
+        st = env.status.cpu().numpy().copy()
+        assert not (st & 1).any()                                           # no overflow
+        out = (env.sweeps.clone(), env.get_state().clone(), env.get_counters(), st)
+        env.close()
+        return out
+    literal = run(0)
+    assert int(literal[0].max()) > 20
+    for plan in (1, 2, 3):
+        got = run(plan)
+        assert torch.equal(got[0], literal[0]) and torch.equal(got[1], literal[1]), plan
+        assert int(got[2][:, 2].sum()) == 0, plan                                        # no late stop
+    ver = run(1, verify=1)
+    assert torch.equal(ver[0], literal[0]) and not np.any(ver[3] & 4)
+    plan2, plan3 = run(2, over=12), run(3, over=12)
+    assert int(plan2[2][:, 2].sum()) > 0 and int((plan2[0] > literal[0]).sum()) > 0     # the hook does provoke late stops
+    assert int(plan3[2][:, 2].sum()) > 0 and int(plan3[2][:, 3].sum()) == int(plan3[2][:, 2].sum())
+    assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_speculative_first_evaluation_never_changes_a_result(dtype):
     """ns2d_fast_impl.h starts a Jacobi solve with spec_start/8 of the previous timestep's sweep count as double sweeps
@@ -747,12 +797,15 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
 
 @pytest.mark.parametrize("L,H,dtype,tol", [(1.5, 1.0, "f32", 5e-5), (1.5, 1.0, "f64", F64_TOL), (1.06, 1.0, "f32", 5e-5),
                                             (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
-                                            (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL)])
+                                            (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL),
+                                            (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
-    60x120, 110x65 (two rows per lane; odd ny: the last lane holds one row; float64: fields in a global scratch) -- 30 timesteps with distinct actions against the float64 oracle, and against the generic
-    kernel on the same inputs."""
+    60x120, 110x65 (two rows per lane; odd ny: the last lane holds one row; float64: fields in a global scratch), and
+    50x150, 64x200 (ny > 128: ns2d_fast4_impl.h, the Poisson solve in registers with 3 / 4 rows per lane, the transport as
+    a register walk along anti-diagonals) -- 30 timesteps with distinct actions against the float64 oracle, and against
+    the generic kernel on the same inputs."""
     B = 6
     env = V.VecRayleigh(B, DEV, dtype, None, L=L, H=H)
     env.set_ndt_act(30)
@@ -771,7 +824,7 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
         env.check_status()
         out[variant] = (obs.double().cpu().numpy(), rwd.double().cpu().numpy(), dev2ref(env.get_state()), env.sweeps.cpu().numpy())
         if variant == 1:
-            assert env.kernel_name in ("ns2d_fast_step", "ns2d_fast2_step")
+            assert env.kernel_name == ("ns2d_fast4_step" if env.ny > 128 else "ns2d_fast2_step" if env.ny > 64 else "ns2d_fast_step")
     for b in range(B):
         o = O.rayleigh(init=False, L=L, H=H)
         o.cfg.ndt_act = 30
@@ -787,9 +840,10 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     env.close()
 
 
-@pytest.mark.parametrize("H", [1.1, 1.05])
+@pytest.mark.parametrize("H", [1.1, 1.05, 2.0])
 def test_jit_grid_mixing_vs_oracle(H):
     """mixing(L=1.0, H=1.1 / 1.05): 100x110 / 100x105 (odd ny), two rows per lane, strips of 13 columns (the last wave 9);
+    mixing(L=1.0, H=2.0): 100x200, ns2d_fast4_impl.h (15 strips of 7 columns, 4 rows per lane, transport in two row blocks);
     40 timesteps from rest."""
     env = V.VecMixing(4, DEV, "f32", L=1.0, H=H)
     env.set_ndt_act(40)
@@ -798,7 +852,7 @@ def test_jit_grid_mixing_vs_oracle(H):
     a = np.arange(4)
     obs, rwd, _, _, _ = env.step(a)
     env.check_status()
-    assert env.kernel_name == "ns2d_fast2_step"
+    assert env.kernel_name == ("ns2d_fast4_step" if env.ny > 128 else "ns2d_fast2_step")
     st = dev2ref(env.get_state())
     sw = env.sweeps.cpu().numpy()
     for b in range(4):
