@@ -10,7 +10,8 @@
 //    and the explicit part of the transport run over them with lanes along x (coalesced), as in ns2d_generic.hip.
 //  * Poisson: wave w owns the column strip [w R + 1, w R + R], lane l the rows [l RPL + 1, (l+1) RPL]: the vertical
 //    neighbours of a cell are in the lane's own registers except across lanes (one DPP move up, one down per COLUMN),
-//    the horizontal ones in the wave's own registers except at the strip edges, which go through LDS once per sweep
+//    (RPL = ceil(ny / 64); rows past ny in the last lane hold zeros); the horizontal ones in the wave's own registers except
+//    at the strip edges, which go through LDS once per sweep
 //    (RPL contiguous values per lane).  The residual of the reference's stop test (sum over the whole array incl.
 //    ghosts, rayleigh.py:448-449) is evaluated after EVERY sweep, as the reference does; its workgroup reduction shares
 //    the one barrier per sweep with the edge exchange.  16 waves of <= 128 VGPRs: four per SIMD hide each other's
@@ -44,7 +45,8 @@ struct Fast4Geom {
   static constexpr int NW = (NX + R - 1) / R;       // waves = column strips
   static constexpr int RL = NX - (NW - 1) * R;      // columns of the last strip (1..R)
   static constexpr int NT = NW * BCN_WAVE;
-  static constexpr int NL = NY / RPL;               // lanes that hold rows
+  static constexpr int NL = (NY + RPL - 1) / RPL;   // lanes that hold rows (the last one RT + 1 <= RPL of them)
+  static constexpr int RT = (NY - 1) % RPL;         // the top row is row RT of lane NL - 1
   static constexpr int P = SX | 1;                  // LDS pitch of a natural-layout array (odd)
   static constexpr int CPL = (NX + BCN_WAVE - 1) / BCN_WAVE;  // columns per lane of the transport walk
   static constexpr int HROWS = BCN_WAVE * RPL;      // one edge column in the exchange buffer (lane-major)
@@ -60,7 +62,7 @@ struct Fast4Geom {
     const int jac = FIXED + HAL + WARR, tr = FIXED + 3 * P * br(esz);
     return jac > tr ? jac : tr;
   }
-  static_assert(NY % RPL == 0 && NL <= BCN_WAVE, "rows per lane must divide ny");
+  static_assert(NL <= BCN_WAVE, "ny <= 64 rows per lane");
   static_assert(NW >= 2 && NW <= 16 && RL >= 1, "2..16 column strips");
 };
 
@@ -99,7 +101,7 @@ template <typename real> struct F4Tr { real uW, uE, vS, vN, Tc, TE, TN, TW; };
 template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
 __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_step(NS2DArgs<real> A) {
   using G = Fast4Geom<NX, NY, R, RPL>;
-  constexpr int NW = G::NW, NT = G::NT, SX = G::SX, P = G::P, RL = G::RL, NL = G::NL, CPL = G::CPL, HROWS = G::HROWS;
+  constexpr int NW = G::NW, NT = G::NT, SX = G::SX, P = G::P, RL = G::RL, NL = G::NL, RT = G::RT, CPL = G::CPL, HROWS = G::HROWS;
   constexpr int BR = G::br(sizeof(real)), NBLK = G::nblk(sizeof(real));
 #ifndef BCN_F4_U
 #define BCN_F4_U 2
@@ -170,9 +172,15 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
 
   // ---- Poisson mapping: wave = column strip, lane = RPL rows ----
   const bool lastw = (w == NW - 1);
-  const bool rowsl = tx < NL;
+  bool rowok[RPL];                 // rows past ny (the last lane's, where RPL does not divide ny) hold phi = 0 and stay there
+  real cxr[RPL], cyr[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; r++) {
+    rowok[r] = tx * RPL + r < NY;
+    cxr[r] = rowok[r] ? A.cx : real(0);
+    cyr[r] = rowok[r] ? A.cy : real(0);
+  }
   const int i0 = 1 + w * R, j0l = 1 + tx * RPL;
-  const real cxl = rowsl ? A.cx : real(0), cyl = rowsl ? A.cy : real(0);
   const real tmask = (KIND == 0 && tx == NL - 1) ? real(1) : real(0);   // Neumann top wall (rayleigh); mixing: phi = 0 above
   const real bmask = (tx == 0) ? real(1) : real(0);
   // exchange slots: west edge -> east halo of the strip to the left (own west halo at the wall: Neumann), and vice versa
@@ -275,7 +283,7 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
     for (int k = 0; k < R; k++)
 #pragma unroll
       for (int r = 0; r < RPL; r++) {
-        const bool ok = rowsl && (k < RL || !lastw);
+        const bool ok = rowok[r] && (k < RL || !lastw);
         Bv[k][r] = ok ? W[(j0l + r) * P + i0 + k] : real(0);
       }
     int itp = 0, par = 0;
@@ -307,19 +315,19 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
           for (int r = 0; r < RPL; r++) cur[r] = Pv[k][r];                                                                         \
           const real sdn = from_below<real>(cur[0], cur[RPL - 1]);                                                                 \
           real nup = dpp<0x130, 0xf, 0xf, true>(real(0), cur[0]);                                                                  \
-          if constexpr (KIND == 0) nup = tmask * cur[RPL - 1] + nup;                                                               \
       _Pragma("unroll")                                                                                                            \
           for (int r = 0; r < RPL; r++) {                                                                                          \
             const real s = (r == 0) ? sdn : cur[r - 1];                                                                            \
-            const real n = (r == RPL - 1) ? nup : cur[r + 1];                                                                      \
+            real n = (r == RPL - 1) ? nup : cur[r + 1 < RPL ? r + 1 : r];                                                          \
+            if (KIND == 0 && r == RT) n = tmask * cur[r] + n;                                                                      \
             real e;                                                                                                                \
             if (k == R - 1) e = east[r];                                                                                           \
             else if (k == RL - 1) e = lastw ? east[r] : Pv[k + 1 < R ? k + 1 : k][r];                                              \
             else e = Pv[k + 1 < R ? k + 1 : k][r];                                                                                 \
             const real wv = west[r];                                                                                               \
             real ph;                                                                                                               \
-            if constexpr (EQ) ph = cxl * ((e + wv) + (n + s)) + Bv[k][r];                                                          \
-            else ph = cyl * (n + s) + (cxl * (e + wv) + Bv[k][r]);                                                                 \
+            if constexpr (EQ) ph = cxr[r] * ((e + wv) + (n + s)) + Bv[k][r];                                                       \
+            else ph = cyr[r] * (n + s) + (cxr[r] * (e + wv) + Bv[k][r]);                                                               \
             if (EV) {                                                                                                              \
               const real d = ph - cur[r];                                                                                          \
               acc[r] += d * d;                                                                                                     \
@@ -342,7 +350,7 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
       _Pragma("unroll")                                                                                                            \
         for (int r = 0; r < RPL; r++) plain += acc[r];                                                                             \
         real loc = plain + bmask * acc[0];                                                                                         \
-        if constexpr (KIND == 0) loc += tmask * acc[RPL - 1];                                                                      \
+        if constexpr (KIND == 0) loc += tmask * acc[RT];                                                                           \
         if (w == 0) loc += accW;                                                                                                   \
         if (lastw) loc += accE;                                                                                                    \
         loc = wave_sum_lane63<real>(loc);                                                                                          \
@@ -434,7 +442,7 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
     for (int k = 0; k < R; k++)
 #pragma unroll
       for (int r = 0; r < RPL; r++)
-        if (rowsl && (k < RL || !lastw)) W[(j0l + r) * P + i0 + k] = Pv[k][r];
+        if (rowok[r] && (k < RL || !lastw)) W[(j0l + r) * P + i0 + k] = Pv[k][r];
     __syncthreads();
 
     // ---- p += phi incl. ghosts (rayleigh.py:219), corrector (rayleigh.py:460-464) ----

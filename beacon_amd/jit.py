@@ -75,9 +75,7 @@ def choose(nx, ny, f64, kind):
     if ny <= 256:
         # ns2d_fast4_impl.h: only the Poisson solve lives in registers (rpl rows per lane, strips of r columns); 16 waves of
         # 128 VGPRs where phi, phi' and the rhs of a strip fit them, else 8 waves of 256
-        rpl = next((q for q in (2, 3, 4) if ny % q == 0 and ny // q <= 64), None)
-        if rpl is None:
-            return None
+        rpl = -(-ny // 64)
         for nwmax, words in ((16, 28), (8, 60)):
             if (f64 and nwmax > 8) or nwmax > int(os.environ.get("BEACON_JIT_F4_NWMAX", "16")):   # (the variable: experiments)
                 continue
@@ -188,7 +186,7 @@ def plugin_for(nx, ny, f64, kind):
 TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 64, False, 0), (110, 64, True, 0),
               (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
               (100, 105, False, 1), (50, 70, True, 0), (50, 150, False, 0), (50, 150, True, 0), (64, 200, False, 0),
-              (100, 200, False, 1)]
+              (100, 200, False, 1), (50, 145, False, 0), (50, 149, True, 0), (100, 130, False, 1)]
 
 
 def prebuild(grids=None, verbose=False):

@@ -11,12 +11,17 @@ from beacon_amd.vec import VecMixing, VecRayleigh
 
 
 def run(env, acts, n=2):
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def draw():                      # integer actions (mixing): a new random wall motion every step, as bench.py does
+        return torch.randint(0, 4, acts.shape, generator=g, device="cuda", dtype=torch.int32) if acts.dtype == torch.int32 else acts
     env.reset()
-    env.step(acts)
+    for _ in range(3):
+        env.step(draw())
     torch.cuda.synchronize()
     t = time.time()
     for _ in range(n):
-        env.step(acts)
+        env.step(draw())
     torch.cuda.synchronize()
     ms = (time.time() - t) / n * 1e3
     sw = env.sweeps.double().cpu().numpy()
@@ -30,7 +35,7 @@ def run(env, acts, n=2):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
-for name, mk, act in (("mixing 100x200", lambda: VecMixing(B, dtype=torch.float32, L=1.0, H=2.0), lambda e: torch.zeros(B, dtype=torch.int32, device="cuda")),
+for name, mk, act in (("mixing 100x200", lambda: VecMixing(B, dtype=torch.float32, L=1.0, H=2.0), lambda e: (torch.arange(B, dtype=torch.int32, device="cuda") % 4)),
                       ("rayleigh 50x150", lambda: VecRayleigh(B, dtype=torch.float32, L=1.0, H=3.0), lambda e: torch.zeros(B, e.n_sgts, dtype=torch.float32, device="cuda")),
                       ("rayleigh 50x150 f64", lambda: VecRayleigh(B, dtype=torch.float64, L=1.0, H=3.0), lambda e: torch.zeros(B, e.n_sgts, dtype=torch.float64, device="cuda")),
                       ("mixing 100x100", lambda: VecMixing(B, dtype=torch.float32), lambda e: torch.zeros(B, dtype=torch.int32, device="cuda"))):

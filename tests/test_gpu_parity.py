@@ -798,13 +798,14 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
 @pytest.mark.parametrize("L,H,dtype,tol", [(1.5, 1.0, "f32", 5e-5), (1.5, 1.0, "f64", F64_TOL), (1.06, 1.0, "f32", 5e-5),
                                             (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
                                             (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL),
-                                            (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5)])
+                                            (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5),
+                                            (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
     60x120, 110x65 (two rows per lane; odd ny: the last lane holds one row; float64: fields in a global scratch), and
-    50x150, 64x200 (ny > 128: ns2d_fast4_impl.h, the Poisson solve in registers with 3 / 4 rows per lane, the transport as
-    a register walk along anti-diagonals) -- 30 timesteps with distinct actions against the float64 oracle, and against
+    50x150, 64x200, 50x145, 50x149 (ny > 128: ns2d_fast4_impl.h, the Poisson solve in registers with 3 / 4 rows per lane
+    -- the last lane holding 1 or 2 rows where 3 does not divide ny --, the transport as a register walk along anti-diagonals) -- 30 timesteps with distinct actions against the float64 oracle, and against
     the generic kernel on the same inputs."""
     B = 6
     env = V.VecRayleigh(B, DEV, dtype, None, L=L, H=H)
@@ -840,10 +841,11 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     env.close()
 
 
-@pytest.mark.parametrize("H", [1.1, 1.05, 2.0])
+@pytest.mark.parametrize("H", [1.1, 1.05, 2.0, 1.3])
 def test_jit_grid_mixing_vs_oracle(H):
     """mixing(L=1.0, H=1.1 / 1.05): 100x110 / 100x105 (odd ny), two rows per lane, strips of 13 columns (the last wave 9);
-    mixing(L=1.0, H=2.0): 100x200, ns2d_fast4_impl.h (15 strips of 7 columns, 4 rows per lane, transport in two row blocks);
+    mixing(L=1.0, H=2.0 / 1.3): 100x200 / 100x130, ns2d_fast4_impl.h (15 strips of 7 columns, 4 / 3 rows per lane, transport in
+    two row blocks / one);
     40 timesteps from rest."""
     env = V.VecMixing(4, DEV, "f32", L=1.0, H=H)
     env.set_ndt_act(40)
