@@ -50,7 +50,7 @@ struct Fast4Geom {
   static constexpr int P = SX | 1;                  // LDS pitch of a natural-layout array (odd)
   static constexpr int CPL = (NX + BCN_WAVE - 1) / BCN_WAVE;  // columns per lane of the transport walk
   static constexpr int HROWS = BCN_WAVE * RPL;      // one edge column in the exchange buffer (lane-major)
-  static constexpr int FIXED = 2 * 32 + 64;         // reduction scratch [2][2][16] + conditioned actions
+  static constexpr int FIXED = 2 * 32 + 64 + 16;    // reduction scratch [2][2][16] + conditioned actions + the scheduler's two words
   static constexpr int HAL = 2 * NW * 2 * HROWS;    // [parity][wave][west|east][HROWS]
   static constexpr int WARR = P * (NY + 2);
   static constexpr int LDS_ELEMS_MAX(int esz) { return 160 * 1024 / esz; }
@@ -98,8 +98,11 @@ template <typename real> struct F4Rhs { real u0, u1, v0, v1; };
 template <typename real> struct F4Corr { real p, us, vs, gx, gy; };
 template <typename real> struct F4Tr { real uW, uE, vS, vN, Tc, TE, TN, TW; };
 
+// timesteps [it_begin, it_end) of replica b: the whole action step (plain launch) or one chunk of it (ticket scheduler,
+// ns2d_sched.h: the replica's state lives in HBM between timesteps anyway, so a chunk needs no load / store of its own)
 template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
-__global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_step(NS2DArgs<real> A) {
+__device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b, const int it_begin, const int it_end,
+                                           const bool first_chunk, const bool last_chunk, char* smem) {
   using G = Fast4Geom<NX, NY, R, RPL>;
   constexpr int NW = G::NW, NT = G::NT, SX = G::SX, P = G::P, RL = G::RL, NL = G::NL, RT = G::RT, CPL = G::CPL, HROWS = G::HROWS;
   constexpr int BR = G::br(sizeof(real)), NBLK = G::nblk(sizeof(real));
@@ -107,18 +110,15 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
 #define BCN_F4_U 2
 #endif
   constexpr int U = (CPL >= BCN_F4_U) ? 1 : BCN_F4_U / CPL;   // rows of a lane in flight in the HBM/L2 phases
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x;
-  if (A.mask && !A.mask[b]) return;
   const int tid = threadIdx.x;
   const int tx = tid & (BCN_WAVE - 1), w = tid >> 6;
   const size_t off = (size_t)b * G::NCELL;
 
   real* red = reinterpret_cast<real*>(smem);  // [2][2][16]
-  real* sact = red + 2 * 32;                  // [64] conditioned actions
-  real* hal = sact + 64;                      // Poisson: edge-column exchange
+  real* sact = red + 2 * 32;                  // [64] conditioned actions ([128..129]: the scheduler's words)
+  real* hal = red + G::FIXED;                     // Poisson: edge-column exchange
   real* W = hal + G::HAL;                     // Poisson: -rhs in, phi out (natural layout, pitch P)
-  real* TX = sact + 64;                       // transport (overlays the two above): A -> S', aW, aS of one row block
+  real* TX = red + G::FIXED;                     // transport (overlays the two above): A -> S', aW, aS of one row block
   real* TY = TX + BR * P;
   real* TZ = TY + BR * P;
 
@@ -141,7 +141,9 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
   if (tid < 2 * 32) red[tid] = 0;
   // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----
   real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
-  if constexpr (KIND == 0) {
+  if (KIND == 0 && !first_chunk) {   // later chunks of a scheduled step reuse the conditioned vector
+    if (tid < A.n_sgts) sact[tid] = A.a_last[(size_t)b * A.n_sgts + tid];
+  } else if constexpr (KIND == 0) {
     const int n = A.n_sgts;
     const real* src = A.actions ? A.actions + (size_t)b * n : A.a_last + (size_t)b * n;
     real mean = 0;
@@ -160,9 +162,9 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
       if (A.actions_norm) A.actions_norm[(size_t)b * n + tid] = mine;
     }
   } else {
-    int act = A.iactions ? A.iactions[b] : A.ia_last[b];
+    const int act = (A.iactions && first_chunk) ? A.iactions[b] : A.ia_last[b];
     __syncthreads();
-    if (tid == 0) A.ia_last[b] = act;
+    if (tid == 0 && first_chunk) A.ia_last[b] = act;
     if (act == 0) { u_b = A.u_max; u_t = -A.u_max; }
     if (act == 1) { u_b = -A.u_max; u_t = A.u_max; }
     if (act == 2) { v_r = A.u_max; v_l = -A.u_max; }
@@ -190,8 +192,8 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
   real* const he_wr0 = hal + ((lastw ? w * 2 + 1 : (w + 1) * 2 + 0)) * HROWS + tx * RPL;
   constexpr int HPAR = NW * 2 * HROWS;
 
-  int status = 0;
-  for (int it = 0; it < A.ndt_act && status == 0; it++) {
+  int status = first_chunk ? 0 : A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
+  for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions (rayleigh.py:180-202 / mixing.py:153-171) ----
     BCN_F4_PH(7)
     for (int j = 1 + tid; j <= NY; j += NT) {
@@ -560,18 +562,40 @@ __global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_st
     }
   }
 
-  if (A.cyc && tid == 0) {
-    A.cyc[(size_t)b * 4 + 0] = t_jac;
-    A.cyc[(size_t)b * 4 + 1] = __builtin_amdgcn_s_memtime() - t_begin;
+  if (A.cyc && tid == 0) {   // a replica's chunks run one after the other (hand-off through the progress word): plain +=
+    A.cyc[(size_t)b * 4 + 0] += t_jac;
+    A.cyc[(size_t)b * 4 + 1] += __builtin_amdgcn_s_memtime() - t_begin;
 #ifdef BCN_F4_STAMP
-    A.cyc[(size_t)b * 4 + 2] = t_ph;
-    A.cyc[(size_t)b * 4 + 3] = n_eval;
+    A.cyc[(size_t)b * 4 + 2] += t_ph;
+    A.cyc[(size_t)b * 4 + 3] += n_eval;
 #else
-    A.cyc[(size_t)b * 4 + 2] = n_late;   // stops the extrapolating plan did not foresee
-    A.cyc[(size_t)b * 4 + 3] = n_redo;   // solves repeated under the proven plan (conv_plan 3)
+    A.cyc[(size_t)b * 4 + 2] += n_late;   // stops the extrapolating plan did not foresee
+    A.cyc[(size_t)b * 4 + 3] += n_redo;   // solves repeated under the proven plan (conv_plan 3)
 #endif
   }
-  ns2d_finish<real, NT>(A, b, u, v, S, status, red);
+  if (last_chunk) {
+    ns2d_finish<real, NT>(A, b, u, v, S, status, red);
+  } else if (tid == 0) {
+    A.status[b] = status;
+  }
+}
+
+template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
+__global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_step(NS2DArgs<real> A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (A.mask && !A.mask[b]) return;
+  fast4_unit<real, NX, NY, R, RPL, KIND, EQ>(A, b, 0, A.ndt_act, true, true, smem);
+}
+
+// ticketed chunk scheduler (ns2d_sched.h): persistent workgroups draw (chunk, replica) units
+template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
+__global__ __launch_bounds__((Fast4Geom<NX, NY, R, RPL>::NT)) void ns2d_fast4_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) + 128);
+  ns2d_sched_loop<real>(A, ctl, batch, nchunk, s_words, [&](int b, int it0, int it1, bool first, bool last) {
+    fast4_unit<real, NX, NY, R, RPL, KIND, EQ>(A, b, it0, it1, first, last, smem);
+  });
 }
 
 template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
@@ -580,6 +604,22 @@ int launch_fast4_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   const size_t lds = (size_t)G::lds_elems(sizeof(real)) * sizeof(real);
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
+  const SchedParams sp = ns2d_sched_params(a);
+  const int q = sp.q_set ? sp.q : 20;   // timesteps per chunk
+  if (sp.mode == 2 && batch > sp.grid && a.ndt_act >= 2 * q && a.sched_ctl) {
+    // more replicas than CUs: persistent workgroups share the replicas' timesteps chunk by chunk, so that a CU is not
+    // stuck with the sum of whichever two replicas' sweep counts it was dealt
+    auto ks = ns2d_fast4_sched<real, NX, NY, R, RPL, KIND, EQ>;
+    static unsigned long long set2 = 0;
+    if (ns2d_first_on_device(set2)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c.sched_nbig = 0;
+    c.sched_q = q;
+    BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
+    hipLaunchKernelGGL(ks, dim3(sp.grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, a.ndt_act / q);
+    BCN_HIP(hipGetLastError());
+    if (a.launched) *a.launched = "ns2d_fast4_sched";
+    return BCN_OK;
+  }
   if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
   auto k = ns2d_fast4_step<real, NX, NY, R, RPL, KIND, EQ>;
   static unsigned long long set = 0;

@@ -84,11 +84,11 @@ def choose(nx, ny, f64, kind):
             if nw < 2 or r * rpl * (2 if f64 else 1) > words:
                 continue
             pitch = (nx + 2) | 1
-            cap = (LDS_BYTES // esz - 128) // (3 * pitch)
+            cap = (LDS_BYTES // esz - 144) // (3 * pitch)
             if cap < 1:
                 continue
             nblk = -(-ny // cap)
-            lds = (128 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk))) * esz
+            lds = (144 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk))) * esz
             if lds <= LDS_BYTES:
                 return {"rows": 4, "R": r, "gf": 0, "nw": nw, "rpl": rpl}
     return None

@@ -769,6 +769,44 @@ def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
     assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
 
 
+@pytest.mark.parametrize("kind", ["rayleigh", "mixing"])
+def test_tall_grid_ticket_scheduler_matches_the_plain_launch(kind):
+    """More replicas than CUs: ns2d_fast4_sched (persistent workgroups drawing 20-timestep chunks of any replica,
+    ns2d_sched.h) must return what one workgroup per replica returns, bit for bit: two action steps at B = 320 with distinct
+    actions (rayleigh 50x150 float32; mixing 100x130)."""
+    B = 320
+    out = {}
+    for sched in (0, 2):
+        if kind == "rayleigh":
+            env = V.VecRayleigh(B, DEV, "f32", None, L=1.0, H=3.0)
+            x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+            st0 = np.zeros((4, env.nx + 2, env.ny + 2))
+            st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]
+            env.set_ndt_act(60)
+            env.reset()
+            env.set_state(np.tile(ref_to_dev(st0)[None], (B, 1, 1, 1)))
+            acts = np.random.default_rng(9).uniform(-1, 1, (2, B, 10))
+        else:
+            env = V.VecMixing(B, DEV, "f32", L=1.0, H=1.3)
+            env.set_ndt_act(60)
+            env.reset()
+            acts = np.random.default_rng(9).integers(0, 4, (2, B))
+        assert env.set_variant(1) == 1
+        env.set_sched(sched)
+        res = []
+        for a in acts:
+            obs, rwd, _, _, _ = env.step(a)
+            env.check_status()
+            res.append((env.sweeps.clone(), obs.clone(), rwd.clone()))
+        assert env.kernel_name == ("ns2d_fast4_sched" if sched == 2 else "ns2d_fast4_step")
+        out[sched] = (res, env.get_state().clone())
+        env.close()
+    for (s0, o0, r0), (s2, o2, r2) in zip(out[0][0], out[2][0]):
+        assert torch.equal(s0, s2) and torch.equal(o0, o2) and torch.equal(r0, r2)
+    assert torch.equal(out[0][1], out[2][1])
+    assert int(out[0][0][1][0].max()) > int(out[0][0][1][0].min())      # the replicas do differ in their sweep counts
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_speculative_first_evaluation_never_changes_a_result(dtype):
     """ns2d_fast_impl.h starts a Jacobi solve with spec_start/8 of the previous timestep's sweep count as double sweeps
