@@ -8,14 +8,14 @@
 //
 //  * u, v, p, S, us, vs stay in HBM/L2 ([ny+2][nx+2], x fastest): boundary conditions, predictor, p += phi, corrector
 //    and the explicit part of the transport run over them with lanes along x (coalesced), as in ns2d_generic.hip.
-//  * Poisson: wave w owns the column strip [w R + 1, w R + R], lane l the rows [l RPL + 1, (l+1) RPL]: the vertical
-//    neighbours of a cell are in the lane's own registers except across lanes (one DPP move up, one down per COLUMN),
-//    (RPL = ceil(ny / 64); rows past ny in the last lane hold zeros); the horizontal ones in the wave's own registers except
-//    at the strip edges, which go through LDS once per sweep
-//    (RPL contiguous values per lane).  The residual of the reference's stop test (sum over the whole array incl.
-//    ghosts, rayleigh.py:448-449) is evaluated after EVERY sweep, as the reference does; its workgroup reduction shares
-//    the one barrier per sweep with the edge exchange.  16 waves of <= 128 VGPRs: four per SIMD hide each other's
-//    DPP / LDS latencies.
+//  * Poisson: wave w owns the column strip [w R + 1, w R + R], lane l the rows [l RPL + 1, (l+1) RPL], RPL = ceil(ny / 64)
+//    (rows past ny in the last lane hold zeros): the vertical neighbours of a cell are in the lane's own registers except
+//    across lanes (one DPP move up, one down per COLUMN), the horizontal ones in the wave's own registers except at the
+//    strip edges, which go through LDS once per sweep (RPL contiguous values per lane, one barrier per sweep).  The
+//    residual of the reference's stop test (sum over the whole array incl. ghosts, rayleigh.py:448-449) is evaluated where
+//    the plan says the test can pass (conv_plan 0: every sweep, as the reference; 1 proven, 2 extrapolated, 3 extrapolated
+//    and guarded -- as in ns2d_fast2_impl.h); its workgroup reduction shares the barrier of the edge exchange.  Up to 16
+//    waves of <= 128 VGPRs: four per SIMD hide each other's DPP / LDS latencies (8 fatter waves measured slower).
 //  * the reference's IN-PLACE transport sweep (rayleigh.py:468-487): S' = A + aW S'(i-1,j) + aS S'(i,j-1).  A, aW, aS are
 //    computed by all waves into LDS (as many rows at a time as fit: two blocks at 100x200 float32); then ONE wave walks
 //    the anti-diagonals d = i + j with lanes along x: the west value is the neighbouring lane's previous result (one
@@ -23,6 +23,8 @@
 //    memory round trip inside the chain; the coefficients of the next diagonal are fetched from LDS (odd pitch: no bank
 //    conflicts along a diagonal) while the current one is computed.
 //
+// More replicas than CUs: the kernel body is a unit over a range of timesteps (the state is in HBM between timesteps anyway)
+// and runs under the ticket scheduler of ns2d_sched.h.  DESIGN.md 4.2c has the measurements and what bounds each phase.
 // Same argument block, state layout, status / sweep-count outputs and episode bookkeeping as the other kernels.
 #pragma once
 #include <stdlib.h>

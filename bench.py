@@ -336,6 +336,19 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
     line("mixing-v0 100x100 B=512 float64", env, ms, algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 8),
          {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
     env.close()
+    # a grid above ny = 128 (the reference takes any L, H: mixing.py:20-28): mixing(L=1, H=2) = 100x200, B=256 -- ns2d_fast4
+    # (Poisson solve in registers, the other phases from HBM/L2; the generic kernel needs 574 ms for this step)
+    env = V.VecMixing(256, dev, "f32", L=1.0, H=2.0)
+    env.reset()
+    k = [0]
+    ai2 = ai[:, :256].contiguous()
+
+    def st2():
+        env.step(ai2[k[0] % 8]); k[0] += 1
+    ms = timed(env, st2, 2, warm=2)
+    line("mixing-v0 L=1 H=2 (100x200) B=256 float32", env, ms, algorithmic_bytes(100, 200, env.sweeps.cpu().numpy(), 4),
+         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+    env.close()
     # burgers N=512 B=1024 (configs[1]): 12 B per cell per timestep
     env = V.VecBurgers(1024, dev, "f32", nx=512)
     env.reset()

@@ -105,5 +105,19 @@ if not args.only or "mixing" in args.only:
          "mean_sweeps_per_timestep": float(sw.mean()), "dtype": "f32"}
     out.append(r); env.close()
 
+if "tall" in args.only:      # a grid above ny = 128 (ns2d_fast4_impl.h): mixing(L=1, H=2) = 100x200, one replica per CU
+    B = 256
+    env = V.VecMixing(B, dev, "f32", L=1.0, H=2.0)
+    env.reset()
+    a = torch.as_tensor(rng.integers(0, 4, (K + 3, B)), dtype=torch.int32, device=dev)
+    Km, Wm = min(K, 3), 3
+    wall, ms = timed(env, lambda k: env.step(a[k]), Km, Wm)
+    sw = env.sweeps.cpu().numpy()
+    bytes_ = env.nx * env.ny * 4.0 * (20.0 * sw.size + 3.0 * float(sw.sum()))
+    r = {"env": "mixing-v0 L=1 H=2 (100x200) B=256", "kernel": env.kernel_name,
+         "env_steps_per_s": B * Km / wall, "launch_ms": ms, "effective_GBps": bytes_ / (ms * 1e-3) / 1e9,
+         "mean_sweeps_per_timestep": float(sw.mean()), "dtype": "f32"}
+    out.append(r); env.close()
+
 for r in out:
     print(json.dumps(r))
