@@ -40,15 +40,40 @@ def _lds_rows1(nx, ny, nw, esz, gf):
     return (front + 3 * sz + back) * esz
 
 
+def _choose4(nx, ny, f64):
+    """ns2d_fast4_impl.h: only the Poisson solve lives in registers (rpl = ceil(ny / 64) rows per lane, strips of r columns); 16
+    waves of 128 VGPRs where phi and the rhs of a strip fit them, else 8 waves of 256; the fields stay in HBM/L2."""
+    esz = 8 if f64 else 4
+    if ny > 256:
+        return None
+    rpl = -(-ny // 64)
+    for nwmax, words in ((16, 28), (8, 60)):
+        if (f64 and nwmax > 8) or nwmax > int(os.environ.get("BEACON_JIT_F4_NWMAX", "16")):   # (the variable: experiments)
+            continue
+        r = -(-nx // nwmax)
+        nw = -(-nx // r)
+        if nw < 2 or r * rpl * (2 if f64 else 1) > words:
+            continue
+        pitch = (nx + 2) | 1
+        cap = (LDS_BYTES // esz - 144) // (3 * pitch)
+        if cap < 1:
+            continue
+        nblk = -(-ny // cap)
+        lds = (144 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk))) * esz
+        if lds <= LDS_BYTES:
+            return {"rows": 4, "R": r, "gf": 0, "nw": nw, "rpl": rpl}
+    return None
+
+
 def choose(nx, ny, f64, kind):
     """Mapping of an nx x ny grid onto one workgroup: dict(rows, R, gf) or None.  Waves: 8 (two per SIMD, 256 VGPRs
-    each) where the strips fit the register file, else 12 or 16; the last wave may take fewer columns (>= 3)."""
+    each) where the strips fit the register file, else 12 or 16; the last wave may take fewer columns (>= 3).
+    Everything in registers / LDS where that fits (rows 1: ny <= 64, rayleigh; rows 2: ny <= 128), else the hybrid of
+    ns2d_fast4_impl.h (rows 4: tall grids, wide grids, mixing below ny = 64)."""
     esz = 8 if f64 else 4
     if nx < 6 or ny < 4:
         return None
-    if ny <= 64 and kind != 0:
-        return None          # ns2d_fast_impl.h (one row per lane) implements the rayleigh boundary conditions only
-    if ny <= 64:
+    if ny <= 64 and kind == 0:      # ns2d_fast_impl.h (one row per lane) implements the rayleigh boundary conditions only
         for nw, rmax in ((8, 16 if f64 else 26), (12, 18), (16, 12), (10, 20), (6, 26), (5, 26), (4, 26), (3, 26), (2, 26)):
             if f64 and nw > 8:
                 continue
@@ -59,8 +84,7 @@ def choose(nx, ny, f64, kind):
             for gf in ((0,) if not f64 else (2, 1)):
                 if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
-        return None
-    if ny <= 128:
+    elif 64 < ny <= 128:
         # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); rayleigh and mixing alike
         for nw, rmax in (((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
             r = -(-nx // nw)
@@ -71,27 +95,7 @@ def choose(nx, ny, f64, kind):
             lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
             if lds <= LDS_BYTES:
                 return {"rows": 2, "R": r, "gf": 1 if f64 else 0, "nw": nw}
-        return None
-    if ny <= 256:
-        # ns2d_fast4_impl.h: only the Poisson solve lives in registers (rpl rows per lane, strips of r columns); 16 waves of
-        # 128 VGPRs where phi, phi' and the rhs of a strip fit them, else 8 waves of 256
-        rpl = -(-ny // 64)
-        for nwmax, words in ((16, 28), (8, 60)):
-            if (f64 and nwmax > 8) or nwmax > int(os.environ.get("BEACON_JIT_F4_NWMAX", "16")):   # (the variable: experiments)
-                continue
-            r = -(-nx // nwmax)
-            nw = -(-nx // r)
-            if nw < 2 or r * rpl * (2 if f64 else 1) > words:
-                continue
-            pitch = (nx + 2) | 1
-            cap = (LDS_BYTES // esz - 144) // (3 * pitch)
-            if cap < 1:
-                continue
-            nblk = -(-ny // cap)
-            lds = (144 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk))) * esz
-            if lds <= LDS_BYTES:
-                return {"rows": 4, "R": r, "gf": 0, "nw": nw, "rpl": rpl}
-    return None
+    return _choose4(nx, ny, f64)
 
 
 def _signature(defs):
@@ -186,7 +190,8 @@ def plugin_for(nx, ny, f64, kind):
 TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 64, False, 0), (110, 64, True, 0),
               (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
               (100, 105, False, 1), (50, 70, True, 0), (50, 150, False, 0), (50, 150, True, 0), (64, 200, False, 0),
-              (100, 200, False, 1), (50, 145, False, 0), (50, 149, True, 0), (100, 130, False, 1)]
+              (100, 200, False, 1), (50, 145, False, 0), (50, 149, True, 0), (100, 130, False, 1),
+              (300, 50, False, 0), (200, 100, False, 1)]
 
 
 def prebuild(grids=None, verbose=False):

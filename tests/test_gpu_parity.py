@@ -837,13 +837,14 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
                                             (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
                                             (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL),
                                             (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5),
-                                            (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL)])
+                                            (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL), (6.0, 1.0, "f32", 5e-5)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
     60x120, 110x65 (two rows per lane; odd ny: the last lane holds one row; float64: fields in a global scratch), and
     50x150, 64x200, 50x145, 50x149 (ny > 128: ns2d_fast4_impl.h, the Poisson solve in registers with 3 / 4 rows per lane
-    -- the last lane holding 1 or 2 rows where 3 does not divide ny --, the transport as a register walk along anti-diagonals) -- 30 timesteps with distinct actions against the float64 oracle, and against
+    -- the last lane holding 1 or 2 rows where 3 does not divide ny --, the transport as a register walk along anti-diagonals),
+    and 300x50 (too wide for the one-row-per-lane kernel's registers: the same hybrid with one row per lane, 16 strips of 19 columns) -- 30 timesteps with distinct actions against the float64 oracle, and against
     the generic kernel on the same inputs."""
     B = 6
     env = V.VecRayleigh(B, DEV, dtype, None, L=L, H=H)
@@ -863,7 +864,10 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
         env.check_status()
         out[variant] = (obs.double().cpu().numpy(), rwd.double().cpu().numpy(), dev2ref(env.get_state()), env.sweeps.cpu().numpy())
         if variant == 1:
-            assert env.kernel_name == ("ns2d_fast4_step" if env.ny > 128 else "ns2d_fast2_step" if env.ny > 64 else "ns2d_fast_step")
+            from beacon_amd import jit
+            rows = jit.choose(env.nx, env.ny, dtype == "f64", 0)["rows"]
+            assert rows == (4 if env.ny > 128 or env.nx > 208 else 2 if env.ny > 64 else 1)
+            assert env.kernel_name == {1: "ns2d_fast_step", 2: "ns2d_fast2_step", 4: "ns2d_fast4_step"}[rows]
     for b in range(B):
         o = O.rayleigh(init=False, L=L, H=H)
         o.cfg.ndt_act = 30
@@ -879,24 +883,25 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     env.close()
 
 
-@pytest.mark.parametrize("H", [1.1, 1.05, 2.0, 1.3])
-def test_jit_grid_mixing_vs_oracle(H):
+@pytest.mark.parametrize("L,H", [(1.0, 1.1), (1.0, 1.05), (1.0, 2.0), (1.0, 1.3), (2.0, 1.0)])
+def test_jit_grid_mixing_vs_oracle(L, H):
     """mixing(L=1.0, H=1.1 / 1.05): 100x110 / 100x105 (odd ny), two rows per lane, strips of 13 columns (the last wave 9);
     mixing(L=1.0, H=2.0 / 1.3): 100x200 / 100x130, ns2d_fast4_impl.h (15 strips of 7 columns, 4 / 3 rows per lane, transport in
-    two row blocks / one);
+    two row blocks / one); mixing(L=2.0, H=1.0): 200x100 (wider than the two-rows-per-lane kernel's registers take): the
+    same hybrid with 2 rows per lane, 16 strips of 13 columns, 4 columns per lane in the transport walk;
     40 timesteps from rest."""
-    env = V.VecMixing(4, DEV, "f32", L=1.0, H=H)
+    env = V.VecMixing(4, DEV, "f32", L=L, H=H)
     env.set_ndt_act(40)
     assert env.set_variant(1) == 1 and getattr(env, "_plugin", None) is not None
     env.reset()
     a = np.arange(4)
     obs, rwd, _, _, _ = env.step(a)
     env.check_status()
-    assert env.kernel_name == ("ns2d_fast4_step" if env.ny > 128 else "ns2d_fast2_step")
+    assert env.kernel_name == ("ns2d_fast4_step" if env.ny > 128 or env.nx > 128 else "ns2d_fast2_step")
     st = dev2ref(env.get_state())
     sw = env.sweeps.cpu().numpy()
     for b in range(4):
-        o = O.mixing(L=1.0, H=H)
+        o = O.mixing(L=L, H=H)
         o.cfg.ndt_act = 40
         o.reset()
         ob, rw, _, _, _ = o.step(int(a[b]))
