@@ -24,10 +24,13 @@ class ReplicaSharder(object):
     """Collectives of one sharded env batch.  Pure torch.distributed: works on CPU tensors with
     gloo (tests) and on device tensors with nccl/RCCL (production)."""
 
-    def __init__(self, local_batch, group=None):
+    def __init__(self, local_batch, group=None, always_collective=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # a world of one rank normally skips the collectives; always_collective sends its scatter / gather through the
+        # backend all the same (the one-GPU rehearsal of the RCCL path: tests/test_gpu_parity.py)
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
         self.local_batch = int(local_batch)
         self.global_batch = self.local_batch * self.world
         self._bufs = {}
@@ -35,7 +38,7 @@ class ReplicaSharder(object):
     def scatter_actions(self, actions_global, like):
         """rank 0 holds actions_global[B_global, ...]; every rank returns its [B_local, ...] slice.
         `like`: a tensor giving shape[1:], dtype and device of the local slice."""
-        if self.world == 1:
+        if not self.collective:
             return actions_global
         out = torch.empty((self.local_batch,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
         chunks = None
@@ -48,7 +51,7 @@ class ReplicaSharder(object):
     def gather(self, name, local):
         """Gather one per-replica tensor to rank 0 -> [world, ...local.shape] there, None elsewhere.
         Receive buffers are allocated once per name and reused."""
-        if self.world == 1:
+        if not self.collective:
             return local.unsqueeze(0)
         local = local.contiguous()
         bufs = None
@@ -88,9 +91,9 @@ class ShardedVecEnv(object):
     stream; `seed` defaults to the seed the env itself was constructed with (VecBurgers(seed=...)), and an
     unsharded env (world size 1) keeps its generator untouched."""
 
-    def __init__(self, local_env, group=None, seed=None):
+    def __init__(self, local_env, group=None, seed=None, always_collective=False):
         self.env = local_env
-        self.sh = ReplicaSharder(local_env.batch, group)
+        self.sh = ReplicaSharder(local_env.batch, group, always_collective)
         self.global_batch = self.sh.global_batch
         self.lo, self.hi = shard_bounds(self.global_batch, self.sh.world, self.sh.rank)
         self.status = None
@@ -119,7 +122,7 @@ class ShardedVecEnv(object):
     def step(self, actions_global=None, noise=None, scattered=False):
         """actions_global: full [B_global, ...] on rank 0 (ignored elsewhere) unless
         scattered=True, in which case every rank passes its own local slice."""
-        if scattered or self.sh.world == 1:
+        if scattered or not self.sh.collective:
             local = actions_global
         else:
             local = self.sh.scatter_actions(actions_global, self._like_actions())

@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--zero-actions", action="store_true",
                     help="diagnostic: uncontrolled steady flow (1 Jacobi sweep per timestep) -> non-Poisson cost")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo with --stub)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on a one-GPU box: with --gpus 1, run the process group, barriers, reductions and the packed "
+                         "gather of the N > 1 path through the backend all the same (a world of one rank over RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; nccl needs one device per rank)")
     ap.add_argument("--L", type=float, default=2.56, help="domain length (nx = 50 L; rayleigh.py:26)")
@@ -405,9 +408,14 @@ def main():
     if fault is not None and int(fault) == rank:
         sys.stderr.write("bench.py: injected fault on rank %d\n" % rank)
         os._exit(3)
-    if world > 1:
+    distc = world > 1 or args.force_dist         # the collectives run (always when there is more than one rank)
+    if distc:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29751")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         tmo = datetime.timedelta(seconds=args.dist_timeout)
         if args.stub or args.backend != "nccl":
             dist.init_process_group(args.backend, timeout=tmo)
@@ -448,7 +456,7 @@ def main():
         return e
 
     env = make_env(B)
-    senv = ShardedVecEnv(env)
+    senv = ShardedVecEnv(env, always_collective=args.force_dist)
     # one global action stream, every rank takes the slice of its replicas (weak: a longer stream)
     acts_g = np.random.default_rng(1234).uniform(-1.0, 1.0, (W + K, Bg, env.n_sgts))
     if args.zero_actions:
@@ -460,7 +468,7 @@ def main():
     def sync():
         if not args.stub:
             torch.cuda.synchronize()
-        if world > 1:
+        if distc:
             dist.barrier()
         if not args.stub:
             torch.cuda.synchronize()
@@ -483,24 +491,24 @@ def main():
         if use_ev:
             ev[k][1].record()
         sweeps_all.append(env.sweeps.clone())       # tiny device copy, for the roofline accounting
-        if world > 1:                               # trainer-facing gather (one collective), inside the timed region
+        if distc:                                   # trainer-facing gather (one collective), inside the timed region
             senv._gather()
     sync()
     elapsed = time.perf_counter() - t0
     env.check_status()
     cyc = env.get_counters().astype(np.float64)     # of the last step
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distc:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
 
     # N > 1, weak scaling: one more short timed loop with the GLOBAL batch of --batch replicas sharded over the ranks,
     # so that one invocation carries both readings of "batch=512 at 1/2/4/8 GPUs" (same barriers, max over ranks)
     strong = None
-    if world > 1 and args.scaling == "weak" and not args.no_strong and args.batch % world == 0:
+    if distc and args.scaling == "weak" and not args.no_strong and args.batch % world == 0:
         Bs, Ks, Ws = args.batch // world, min(K, 5), 1
         env_s = make_env(Bs)
-        senv_s = ShardedVecEnv(env_s)
+        senv_s = ShardedVecEnv(env_s, always_collective=args.force_dist)
         a_s = np.random.default_rng(1234).uniform(-1.0, 1.0, (Ws + Ks, args.batch, env_s.n_sgts))[:, senv_s.lo:senv_s.hi]
         a_s = torch.as_tensor(a_s, dtype=env_s.tdtype, device=dev)
         senv_s.reset()
@@ -589,7 +597,7 @@ def main():
             out["secondary"] = secondary_lines(dev, acts_np, W, init, (L, H))
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if distc:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1889,6 +1889,80 @@ print("rank", rank, "ok")
 """
 
 
+_RCCL_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from beacon_amd import vec as V
+from beacon_amd.dist import ShardedVecEnv
+from beacon_amd.envs import packaged_init
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev, B = "cuda:0", 6
+rng = np.random.default_rng(5)
+for name in ("rayleigh", "burgers"):
+    def make():
+        if name == "rayleigh":
+            e = V.VecRayleigh(B, dev, "f32", packaged_init("rayleigh")); e.set_ndt_act(20); return e
+        return V.VecBurgers(B, dev, "f32", nx=512)
+    senv = ShardedVecEnv(make(), always_collective=True)
+    assert senv.sh.collective and senv.sh.world == 1
+    o0 = senv.reset()[0].clone()       # (outputs are views of the receive buffer: valid until the next step, as VecEnv's)
+    acts = torch.as_tensor(rng.uniform(-1, 1, (3, B, 10) if name == "rayleigh" else (3, B)), dtype=torch.float32)
+    noise = None if name == "rayleigh" else torch.zeros((B,), dtype=torch.float32, device=dev)
+    outs = [tuple(x.clone() if x is not None else None for x in senv.step(acts[k], noise)) for k in range(3)]
+    ref = make()
+    ref.reset()
+    assert torch.equal(o0, ref.obs), name
+    for k in range(3):
+        obs, rwd, done, trunc, _ = ref.step(acts[k], noise)
+        o, r, d, t, _ = outs[k]
+        assert o.is_cuda and o.shape == obs.shape and torch.equal(o, obs) and torch.equal(r, rwd) and torch.equal(d, done), (name, k)
+    assert int(senv.gather_status().max()) == 0
+    ref.close(); senv.close()
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok", torch.cuda.nccl.version())
+"""
+
+
+def test_one_rank_through_rccl(tmp_path):
+    """The production backend on the box's one GPU: a world of ONE rank whose scatter and packed gather are forced through
+    torch.distributed's "nccl" backend (= RCCL on ROCm) instead of being skipped -- communicator set-up, a send / receive to
+    itself per collective, device buffers.  Two ranks cannot share a GPU under RCCL (that is the gloo test below); more
+    than one device is the driver's bench.  Results must equal the plain env's bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_bench_multi_gpu_path_over_rccl_with_one_rank():
+    """`bench.py --force-dist`: the N > 1 code path of the bench (process group on the "nccl" backend with the device id,
+    barriers and the max-reduction around the timed region, the packed gather inside it, the strong-scaling loop) with a
+    world of ONE rank on the box's one GPU, self-launched and under torch.distributed.run as the driver starts it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-secondary"]
+    for cmd in ([sys.executable] + common,
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", "29757"] + common):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+        r = subprocess.run(cmd, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 1000 and d["config"]["kernel"] == "ns2d_fast_sched"
+        assert d["strong"]["global_batch"] == 512 and d["strong"]["value"] > 1000
+
+
 def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
     """ShardedVecEnv end to end with the real kernels: rank 0 scatters the global actions, every rank steps its shard on
     the GPU, one packed gather brings obs / rwd / status / done / trunc back -- bit-identical to one process stepping the
