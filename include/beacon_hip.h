@@ -176,11 +176,12 @@ BCN_API int bcn_set_variant(bcn_env_t h, int variant);
  *   [0] shader-clock cycles inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463), [1] in the whole replica,
  *   [2] "late stops": solves whose passing evaluation of the residual directly followed sweeps that the extrapolating
  *       plan (conv_plan 2 / 3) had skipped -- the plan did not foresee the stop, so an earlier sweep may have passed too,
- *   [3] timesteps (rayleigh) / solves (two-rows-per-lane kernels) that were repeated: a speculative jump that went too
+ *   [3] timesteps (rayleigh) / solves (two-rows-per-lane and tall-grid kernels) that were repeated: a speculative jump that went too
  *       far, or conv_plan 3 repeating a late stop under the proven plan.
  * Zeros for kernels that do not count (generic 2D kernel, 1D envs). */
 BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
-/* Register-resident kernel for a grid that is not built into the library.  The reference takes any L, H
+/* Register-resident kernel for a grid that is not built into the library (up to ny = 256; above ny = 128 and for grids wider
+ * than the all-in-registers kernels' strips only the Poisson solve is register-resident: csrc/ns2d_fast4_impl.h).  The reference takes any L, H
  * (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: 100 L, 100 H); csrc/jit/ns2d_jit.hip is compiled for ONE
  * grid into its own shared object (beacon_amd/jit.py does so on demand and caches it) whose
  *   int bcn_jit_launch(const void* step_args, int batch, void* stream)
