@@ -769,6 +769,46 @@ def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
     assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
 
 
+def test_tall_grid_overflow_status_and_replica_mask():
+    """ns2d_fast4_step keeps the other kernels' contract around the solver: a Poisson solve that exceeds itmax sets the
+    status bit that check_status() raises on (the reference prints and exit(1)s: rayleigh.py:451-454), also when a late
+    chunk of a scheduled step meets it; a masked step leaves the skipped replicas' fields, observations and episode
+    counters untouched."""
+    for B, sched in ((2, 0), (288, 2)):
+        env = V.VecRayleigh.__new__(V.VecRayleigh)
+        V.VecRayleigh.__init__(env, B, DEV, "f32", None, L=1.0, H=3.0)
+        env.itmax = 3
+        env.set_ndt_act(40)
+        env.set_sched(sched)
+        env.reset()
+        x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+        st0 = np.zeros((4, env.nx + 2, env.ny + 2))
+        st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x)[:, None] * np.sin(np.pi * y)[None, :]
+        env.set_state(np.tile(ref_to_dev(st0)[None], (B, 1, 1, 1)))
+        env.step(np.tile(np.full((1, 10), 0.7) * np.array([1, -1] * 5), (B, 1)))
+        assert env.kernel_name == ("ns2d_fast4_sched" if sched else "ns2d_fast4_step")
+        assert int((env.status.cpu().numpy() & 1).sum()) == B
+        with pytest.raises(RuntimeError, match="max number of iterations"):
+            env.check_status()
+        env.close()
+    env = V.VecMixing(4, DEV, "f32", L=1.0, H=2.0)
+    env.set_ndt_act(10)
+    env.reset()
+    env.step(np.arange(4))
+    before, obs_b, stp_b = env.get_state().clone(), env.obs.clone(), env.get_stp().copy()
+    mask = np.array([1, 0, 1, 0], dtype=np.uint8)
+    env.step(np.arange(4)[::-1].copy(), mask=mask)
+    env.check_status()
+    assert env.kernel_name == "ns2d_fast4_step"
+    after, stp_a = env.get_state(), env.get_stp()
+    for b in range(4):
+        same = torch.equal(after[b], before[b])
+        assert same == (mask[b] == 0), b
+        assert stp_a[b] == stp_b[b] + int(mask[b])
+    assert torch.equal(env.obs[1], obs_b[1]) and torch.equal(env.obs[3], obs_b[3])
+    env.close()
+
+
 @pytest.mark.parametrize("kind", ["rayleigh", "mixing"])
 def test_tall_grid_ticket_scheduler_matches_the_plain_launch(kind):
     """More replicas than CUs: ns2d_fast4_sched (persistent workgroups drawing 20-timestep chunks of any replica,
