@@ -86,10 +86,12 @@ def choose(nx, ny, f64, kind):
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
     elif 64 < ny <= 128:
         # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); rayleigh and mixing alike
-        for nw, rmax in (((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
+        # (BEACON_JIT_NW: experiments -- only this wave count)
+        only = int(os.environ.get("BEACON_JIT_NW", "0"))
+        for nw, rmax in (((only, 26),) if only else ((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
             r = -(-nx // nw)
             rl = nx - (nw - 1) * r
-            if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
+            if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx or (only and nw != only):
                 continue
             exch = 2 * nw * 4 * 64 + 160
             lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
