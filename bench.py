@@ -257,6 +257,22 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
         env.check_status()
         return float(np.mean([s.elapsed_time(e) for s, e in ev]))
 
+    def timed_loop(env, step, n, warm=5):
+        """n eager step() calls back to back between ONE pair of HIP events: what a trainer's loop pays per call.  (An event
+        pair around EVERY call, as `timed` records for the millisecond-long 2D steps, puts two extra commands between two
+        30 us kernels: burgers 36.9 instead of 32.1 us; the host needs 7.8 us to issue a call -- scripts/host_cost.py.)"""
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            step()
+        e.record()
+        torch.cuda.synchronize()
+        env.check_status()
+        return s.elapsed_time(e) / n
+
     def timed_graph(env, actions, noise=None, n=16, reps=5):
         """The same step recorded n times into one HIP graph (VecEnv.capture): ms per step at replay -- what a trainer
         that records its loop sees instead of the per-launch host work of Python."""
@@ -356,7 +372,7 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
     env = V.VecBurgers(1024, dev, "f32", nx=512)
     env.reset()
     a1 = torch.as_tensor(rng.uniform(-1, 1, (1024,)), dtype=env.tdtype, device=dev)
-    ms = timed(env, lambda: env.step(a1), 50, warm=5)
+    ms = timed_loop(env, lambda: env.step(a1), 200)
     line("burgers-v0 N=512 B=1024 float32 (configs[1])", env, ms, 12.0 * 512 * env.ndt_act * 1024,
          {"ms_per_step_in_hip_graph": timed_graph(env, a1), "inlet_noise": "drawn inside the step kernel (bcn_set_noise)"})
     env.close()
@@ -364,14 +380,14 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
     env = V.VecShkadov(1024, dev, "f32", None, L0=699.2, n_jets=10)
     env.reset()
     a10 = torch.as_tensor(rng.uniform(-1, 1, (1024, 10)), dtype=env.tdtype, device=dev)
-    ms = timed(env, lambda: env.step(a10), 30, warm=5)
+    ms = timed_loop(env, lambda: env.step(a10), 50)
     line("shkadov-v0 N=4096 10 jets B=1024 float32 (configs[2])", env, ms, 32.0 * env.nx * env.ndt_act * 1024,
          {"ms_per_step_in_hip_graph": timed_graph(env, a10), "inlet_noise": "drawn inside the step kernel (bcn_set_noise)"})
     env.close()
     # sloshing (reference default grid) B=1024: 32 B per cell per timestep
     env = V.VecSloshing(1024, dev, "f32", packaged_init("sloshing"))
     env.reset()
-    ms = timed(env, lambda: env.step(a1), 50, warm=5)
+    ms = timed_loop(env, lambda: env.step(a1), 200)
     line("sloshing-v0 N=200 B=1024 float32", env, ms, 32.0 * (env.nx + 2) * env.ndt_act * 1024,
          {"ms_per_step_in_hip_graph": timed_graph(env, a1)})
     env.close()
