@@ -221,6 +221,21 @@ def test_bench_self_launch_and_scalings_on_cpu_stub():
             assert "strong" not in d
 
 
+def test_bench_force_dist_runs_the_collectives_with_one_rank_on_cpu_stub():
+    """`--gpus 1 --force-dist` (the one-GPU rehearsal of the N > 1 path: tests/test_gpu_parity.py runs it over RCCL): a
+    world of one rank still builds the process group and sends its barriers, reductions and the packed gather through the
+    backend; here with the CPU stand-in env over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--batch", "16", "--stub", "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["data"] == "stub" and d["config"]["global_batch"] == 16
+    assert d["strong"]["global_batch"] == 16 and d["strong"]["replicas_per_gpu"] == 16
+
+
 def test_bench_launcher_stops_every_rank_when_one_dies():
     """A rank that dies before the rendezvous (BENCH_FAULT_RANK: os._exit(3) in front of init_process_group) must not
     leave its peer waiting there: the self-launching parent polls all children, terminates the survivors and exits
