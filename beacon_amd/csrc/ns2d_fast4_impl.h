@@ -57,11 +57,11 @@ struct Fast4Geom {
   static constexpr int WARR = P * (NY + 2);
   static constexpr int LDS_ELEMS_MAX(int esz) { return 160 * 1024 / esz; }
   // transport: rows per block and number of blocks
-  static constexpr int br_cap(int esz) { return (LDS_ELEMS_MAX(esz) - FIXED) / (3 * P); }
+  static constexpr int br_cap(int esz) { return (LDS_ELEMS_MAX(esz) - FIXED - 2) / (3 * P); }
   static constexpr int nblk(int esz) { return (NY + br_cap(esz) - 1) / br_cap(esz); }
   static constexpr int br(int esz) { return (NY + nblk(esz) - 1) / nblk(esz); }
   static constexpr int lds_elems(int esz) {
-    const int jac = FIXED + HAL + WARR, tr = FIXED + 3 * P * br(esz);
+    const int jac = FIXED + HAL + WARR, tr = FIXED + 3 * P * br(esz) + 2;
     return jac > tr ? jac : tr;
   }
   static_assert(NL <= BCN_WAVE, "ny <= 64 rows per lane");
@@ -121,8 +121,8 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
   real* hal = red + G::FIXED;                     // Poisson: edge-column exchange
   real* W = hal + G::HAL;                     // Poisson: -rhs in, phi out (natural layout, pitch P)
   real* TX = red + G::FIXED;                     // transport (overlays the two above): A -> S', aW, aS of one row block
-  real* TY = TX + BR * P;
-  real* TZ = TY + BR * P;
+  struct alignas(2 * sizeof(real)) F4YZ { real y, z; };   // aW, aS of a cell side by side: one LDS access in the walk
+  F4YZ* TYZ = reinterpret_cast<F4YZ*>(TX + ((BR * P + 1) & ~1));
 
   real* __restrict__ u = A.u + off;
   real* __restrict__ v = A.v + off;
@@ -497,8 +497,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
           if (ok) {
             const int t = (j - jb0) * P + i;
             TX[t] = xv;
-            TY[t] = aw;
-            TZ[t] = as;
+            TYZ[t] = F4YZ{aw, as};
           }
         });
       __syncthreads();
@@ -518,7 +517,9 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
           for (int q = 0; q < CPL; q++) {
             ok_[q] = (unsigned)t[q] <= (unsigned)len;
             sel_[q] = ok_[q] ? idx[q] : 0;
-            a_[q] = TX[sel_[q]]; y_[q] = TY[sel_[q]]; z_[q] = TZ[sel_[q]];
+            a_[q] = TX[sel_[q]];
+            const F4YZ yz = TYZ[sel_[q]];
+            y_[q] = yz.y; z_[q] = yz.z;
             t[q] += 1;
             idx[q] += P;
           }

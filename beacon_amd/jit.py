@@ -55,11 +55,11 @@ def _choose4(nx, ny, f64):
         if nw < 2 or r * rpl * (2 if f64 else 1) > words:
             continue
         pitch = (nx + 2) | 1
-        cap = (LDS_BYTES // esz - 144) // (3 * pitch)
+        cap = (LDS_BYTES // esz - 146) // (3 * pitch)
         if cap < 1:
             continue
         nblk = -(-ny // cap)
-        lds = (144 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk))) * esz
+        lds = (144 + max(2 * nw * 2 * 64 * rpl + pitch * (ny + 2), 3 * pitch * -(-ny // nblk) + 2)) * esz
         if lds <= LDS_BYTES:
             return {"rows": 4, "R": r, "gf": 0, "nw": nw, "rpl": rpl}
     return None
