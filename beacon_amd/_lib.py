@@ -13,6 +13,7 @@ vp = C.c_void_p
 
 F32, F64 = 0, 1
 ST_OK, ST_ITMAX, ST_BLOWUP, ST_PLAN = 0, 1, 2, 4
+API_VERSION, COUNTER_WORDS = 4, 4          # include/beacon_hip.h: BCN_API_VERSION, BCN_COUNTER_WORDS
 
 
 class RayleighCfg(C.Structure):
@@ -86,6 +87,8 @@ SIGNATURES = {
     "bcn_set_stp": (C.c_int, [vp, c_i32p, vp]),
     "bcn_set_variant": (C.c_int, [vp, C.c_int]),
     "bcn_get_counters": (C.c_int, [vp, C.POINTER(C.c_uint64), vp]),
+    "bcn_get_counters_n": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int, vp]),
+    "bcn_api_version": (C.c_int, []),
     "bcn_set_fast_plugin": (C.c_int, [vp, vp, C.c_size_t]),
     "bcn_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "bcn_set_noise": (C.c_int, [vp, C.c_double, C.c_uint64, C.c_int64]),
@@ -125,6 +128,8 @@ def load():
         fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if L.bcn_api_version() != API_VERSION:
+        raise RuntimeError("libbeacon_hip.so has API version %d, this binding expects %d" % (L.bcn_api_version(), API_VERSION))
     _LIB = L
     return L
 

@@ -65,9 +65,30 @@ def stale():
         return fh.read().strip() != signature()
 
 
+def sweep_objdirs():
+    """Remove the per-process object directories of builders that are gone (a build that was killed leaves its
+    csrc/_obj/p<pid> behind, and the directory ships with every snapshot of the tree)."""
+    if not os.path.isdir(OBJ):
+        return
+    for d in os.listdir(OBJ):
+        if not (d.startswith("p") and d[1:].isdigit()):
+            continue
+        pid = int(d[1:])
+        if pid != os.getpid():
+            try:
+                os.kill(pid, 0)                        # still running: somebody else's build in progress
+                continue
+            except ProcessLookupError:
+                pass
+            except OSError:
+                continue
+        shutil.rmtree(os.path.join(OBJ, d), ignore_errors=True)
+
+
 def build_lib(force=False, verbose=False):
     """Compile every csrc/*.hip for gfx950 and link libbeacon_hip.so.  Returns its path."""
     if not force and not stale():
+        sweep_objdirs()
         return LIB
     cc = hipcc()
     if cc is None:
@@ -102,6 +123,7 @@ def build_lib(force=False, verbose=False):
                 fh.write(sig + "\n")
             os.replace(LIB + ".sig.tmp", LIB + ".sig")
             shutil.rmtree(objdir, ignore_errors=True)
+            sweep_objdirs()
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB

@@ -589,6 +589,18 @@ int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream) {
   DeviceGuard g(h->device);
   return h->get_counters(buf_host, static_cast<hipStream_t>(stream));
 }
+int bcn_get_counters_n(bcn_env_t h, uint64_t* buf_host, int words_per_replica, void* stream) {
+  if (!h || !buf_host || words_per_replica < 1) { bcn_set_error("null handle/buffer or words_per_replica < 1"); return BCN_ERR_ARG; }
+  if (words_per_replica == BCN_COUNTER_WORDS) return bcn_get_counters(h, buf_host, stream);
+  std::vector<uint64_t> tmp((size_t)h->batch * BCN_COUNTER_WORDS);
+  int rc = bcn_get_counters(h, tmp.data(), stream);
+  if (rc) return rc;
+  for (int b = 0; b < h->batch; b++)
+    for (int k = 0; k < words_per_replica; k++)
+      buf_host[(size_t)b * words_per_replica + k] = k < BCN_COUNTER_WORDS ? tmp[(size_t)b * BCN_COUNTER_WORDS + k] : 0;
+  return BCN_OK;
+}
+int bcn_api_version(void) { return BCN_API_VERSION; }
 int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_elems) {
   if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }
   return h->set_fast_plugin(launch_fn, scratch_elems);

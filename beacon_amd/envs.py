@@ -19,7 +19,7 @@ import random
 
 import numpy as np
 
-from . import vec
+from . import spaces, vec
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "init_fields.npz")
 
@@ -352,7 +352,7 @@ class shkadov_separable(shkadov):
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
-        self.observation_space = vec.Box(-1.0, 1.0, (self.n_obs,))
+        self.observation_space = spaces.sym_box(1.0, self.n_obs)           # shkadov.py:394-398
         self.count = 0
         self.act = np.zeros(self.n_jets)
         self._obs_all = np.zeros(self.n_obs * self.n_jets)

@@ -211,8 +211,16 @@ def prebuild(grids=None, verbose=False):
             if f.endswith(".so") and f not in keep and f.rsplit("_", 1)[0] in stems:
                 os.remove(os.path.join(JIT_DIR, f))
             elif f.endswith(".lock"):
+                # a lock file another process holds (flock) must stay: unlinking it would let a third process lock a NEW
+                # file of the same name and compile the same plugin beside the holder
+                lp = os.path.join(JIT_DIR, f)
                 try:
-                    os.remove(os.path.join(JIT_DIR, f))
+                    with open(lp, "r+") as lk:
+                        fcntl.flock(lk, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                        try:
+                            os.remove(lp)
+                        finally:
+                            fcntl.flock(lk, fcntl.LOCK_UN)
                 except OSError:
                     pass
     return paths

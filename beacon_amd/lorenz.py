@@ -4,7 +4,7 @@ Host-only NumPy; it exists to prove the boundary (ctor / reset / step signatures
 actions given as NumPy integers, obs = (x, f(x)) of the LAST RK stage)."""
 import numpy as np
 
-from .vec import Box, Discrete
+from . import spaces
 
 # Carpenter-Kennedy 5-stage 4th-order low-storage RK coefficients (lorenz.py:272-280)
 _A = (0.000000000000000, -0.417890474499852, -1.192151694642677, -1.697784692471528, -1.514183444257156)
@@ -21,9 +21,9 @@ class lorenz(object):
         self.ndt_act = int(self.dt_act / self.dt)
         self.n_act = int(self.t_max / self.dt_act)
         self.x, self.xk, self.fx = np.zeros(3), np.zeros(3), np.zeros(3)
-        self.action_space = Discrete(3)
+        self.action_space = spaces.discrete(3)
         self.actions = np.array([-1.0, 0.0, 1.0])
-        self.observation_space = Box(-1.0, 1.0, (self.n_obs,))
+        self.observation_space = spaces.sym_box(1.0, self.n_obs)
         self.reset_fields()
 
     def reset_fields(self):

@@ -13,32 +13,12 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import spaces
+from .spaces import Box, Discrete   # noqa: F401  (stand-in classes, kept importable from here)
 
 _DT = {"f32": (torch.float32, _lib.F32), "f64": (torch.float64, _lib.F64),
        "float32": (torch.float32, _lib.F32), "float64": (torch.float64, _lib.F64),
        torch.float32: (torch.float32, _lib.F32), torch.float64: (torch.float64, _lib.F64)}
-
-
-class Box(object):
-    """Stand-in for gymnasium.spaces.Box (gymnasium is optional)."""
-
-    def __init__(self, low, high, shape, dtype=np.float32):
-        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape).copy()
-        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape).copy()
-        self.shape, self.dtype = tuple(shape), dtype
-
-    def sample(self, rng=None):
-        rng = rng or np.random.default_rng()
-        return rng.uniform(self.low, self.high).astype(self.dtype)
-
-
-class Discrete(object):
-    def __init__(self, n):
-        self.n, self.shape, self.dtype = n, (), np.int64
-
-    def sample(self, rng=None):
-        rng = rng or np.random.default_rng()
-        return int(rng.integers(0, self.n))
 
 
 def out_layout(batch, obs_dim, esz):
@@ -96,12 +76,48 @@ class VecEnv(object):
     def _alloc_outputs(self):
         """Per-step outputs live in ONE byte buffer [obs | rwd | status | done | trunc] (segments 16-byte
         aligned), so the trainer-facing gather of a sharded batch is a single collective on `out_buf`
-        (beacon_amd/dist.py); obs / rwd / ... are typed views of it."""
+        (beacon_amd/dist.py); obs / rwd / ... are typed views of it.  There may be two such buffers
+        (double_buffer): `out_buf`, `obs`, `rwd`, `status`, `done`, `trunc` always name the one the last
+        reset() / step() wrote."""
         B, esz = self.batch, torch.empty((), dtype=self.tdtype).element_size()
         self.out_layout = out_layout(B, self.obs_dim, esz)
-        self.out_buf = torch.zeros((self.out_layout["bytes"],), dtype=torch.uint8, device=self.device)
-        v = unpack_outputs(self.out_buf, B, self.obs_dim, self.tdtype)
-        self.obs, self.rwd, self.status, self.done, self.trunc = v
+        self.out_bufs, self._views, self._rotate = [], [], False
+        self._add_out_buf()
+        self._bind_outputs(0)
+
+    def _add_out_buf(self):
+        buf = torch.zeros((self.out_layout["bytes"],), dtype=torch.uint8, device=self.device)
+        self.out_bufs.append(buf)
+        self._views.append(unpack_outputs(buf, self.batch, self.obs_dim, self.tdtype))
+
+    def _bind_outputs(self, k):
+        self._cur = k
+        self.out_buf = self.out_bufs[k]
+        self.obs, self.rwd, self.status, self.done, self.trunc = self._views[k]
+
+    def double_buffer(self, on=True):
+        """Alternate between TWO packed output buffers: step k writes buffer k % 2, so that a consumer of step k's
+        outputs on another stream -- the sharded batch's gather to rank 0 (beacon_amd/dist.py), a device-to-host copy --
+        may still be reading them while step k + 1 runs.  After every step() the attributes obs / rwd / done / trunc /
+        status / out_buf are re-bound to the buffer that step wrote (so hold on to the tensors a step RETURNS, not to
+        the attributes, and expect them to be overwritten by the step after next).  reset() writes the current buffer.
+        A step with a replica mask first copies the previous buffer (the rows of skipped replicas keep their values).
+        Not for captured graphs (StepGraph records fixed addresses)."""
+        if on and len(self.out_bufs) == 1:
+            self._add_out_buf()
+        self._rotate = bool(on)
+        if not on:
+            self._bind_outputs(self._cur)
+        return self
+
+    def _next_outputs(self, carry):
+        """Called by step() before the launch: with double buffering, switch to the other buffer."""
+        if not self._rotate:
+            return
+        prev = self.out_buf
+        self._bind_outputs(1 - self._cur)
+        if carry:
+            self.out_buf.copy_(prev)
 
     # -- plumbing ---------------------------------------------------------------------------
     def _stream(self):
@@ -177,16 +193,21 @@ class VecEnv(object):
     def set_noise_seed(self, seed, replica_offset=0):
         """Envs with inlet noise (burgers, shkadov): step() without an explicit `noise` tensor lets the step kernel draw
         uniform(-sigma, sigma) itself (include/beacon_hip.h: bcn_set_noise) -- keyed by `seed`, the global replica index
-        `replica_offset + b`, the replica's count of such steps and the timestep."""
+        `replica_offset + b`, the replica's count of such steps and the timestep.
+        Two things to know: (1) `env.gen` (a torch generator) only feeds draw_noise() and reset_random(); seeding IT does not
+        change the noise of step(a) without a `noise` tensor -- this method does.  (2) sigma, seed and offset are kernel
+        ARGUMENTS: a graph recorded by capture() keeps the values it was recorded with (only the per-replica draw counters
+        live on the device and advance at replay), so re-capture after changing the seed."""
         self.seed, self.replica_offset = int(seed), int(replica_offset)
         _lib.check(self.lib.bcn_set_noise(self.h, float(self.sigma), self.seed, self.replica_offset))
 
     def get_counters(self):
         """uint64 [B, 4] of the last step, per replica: shader cycles inside the Jacobi loop / in the whole replica, late
         stops of the extrapolating residual plan, repeated timesteps (include/beacon_hip.h: bcn_get_counters)."""
-        buf = (C.c_uint64 * (4 * self.batch))()
-        _lib.check(self.lib.bcn_get_counters(self.h, buf, self._stream()))
-        return np.frombuffer(buf, dtype=np.uint64).reshape(self.batch, 4).copy()
+        n = _lib.COUNTER_WORDS
+        buf = (C.c_uint64 * (n * self.batch))()
+        _lib.check(self.lib.bcn_get_counters_n(self.h, buf, n, self._stream()))     # the sized form: the buffer cannot be overrun
+        return np.frombuffer(buf, dtype=np.uint64).reshape(self.batch, n).copy()
 
     @property
     def kernel_name(self):
@@ -227,6 +248,7 @@ class VecEnv(object):
         return self.obs, None
 
     def step(self, actions=None, noise=None, mask=None):
+        self._next_outputs(carry=mask is not None)
         self._apply_mask(mask)
         try:
             self._step(actions, noise)
@@ -244,7 +266,9 @@ class VecEnv(object):
         `actions` (and `noise`): STATIC device tensors the graph reads at every replay -- [B, ...] for one step, or
         [n_steps, B, ...] for n_steps steps (step k uses actions[k]); overwrite them in place between replays.
         keep_steps=False leaves out the per-step copies of obs / rwd / done / trunc (only the last step's stay, in the
-        env's own tensors): every extra graph node costs a few microseconds between two kernels."""
+        env's own tensors): every extra graph node costs a few microseconds between two kernels.
+        The recorded kernels keep the noise seed / sigma they were captured with (set_noise_seed): change the seed, then
+        capture again."""
         return StepGraph(self, actions, noise, n_steps, keep_steps)
 
     def reset_done(self):
@@ -333,10 +357,14 @@ class VecRayleigh(VecEnv):
         self.tol, self.itmax = 1.0e-8, 300000                             # :414-417
         return self
 
+    def _make_spaces(self):
+        self.action_space = spaces.box(-self.C, self.C, (self.n_sgts,))         # rayleigh.py:75-78
+        self.observation_space = spaces.sym_box(1.0, self.n_obs_tot)            # :81-86
+        return self
+
     def _post_init(self):
         n_sgts = self.n_sgts
-        self.action_space = Box(-self.C, self.C, (n_sgts,))
-        self.observation_space = Box(-1.0, 1.0, (self.n_obs_tot,))
+        self._make_spaces()
         self.actions_norm = torch.zeros((self.batch, n_sgts), dtype=self.tdtype, device=self.device)
         self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)
         self._init_dev = None
@@ -418,9 +446,13 @@ class VecMixing(VecEnv):
                  side=0.5, C0=1.0):
         self._derive(L, H, re, pe, side, C0)
         super().__init__(batch, device, dtype)
-        self.action_space = Discrete(4)
-        self.observation_space = Box(-1.0, 1.0, (self.n_obs_tot,))
+        self._make_spaces()
         self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)
+
+    def _make_spaces(self):
+        self.action_space = spaces.discrete(4)                                  # mixing.py:61
+        self.observation_space = spaces.sym_box(1.0, self.n_obs_tot)            # :65-70
+        return self
 
     def _derive(self, L=1.0, H=1.0, re=100.0, pe=10000.0, side=0.5, C0=1.0):
         self.L, self.H, self.re, self.pe, self.side, self.C0 = L, H, re, pe, side, C0
@@ -489,10 +521,14 @@ class VecBurgers(VecEnv):
         self._derive(u_target, amp, sigma, ctrl_pos, L, nx)
         self.seed, self.replica_offset = int(seed), 0
         super().__init__(batch, device, dtype)
-        self.action_space = Box(-1.0, 1.0, (1,))
-        self.observation_space = Box(0.0, 1.0, (self.n_obs_pts,))
+        self._make_spaces()
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(self.seed)
+
+    def _make_spaces(self):
+        self.action_space = spaces.box(-1.0, 1.0, (1,))                         # burgers.py:54-57
+        self.observation_space = spaces.box(np.zeros(self.n_obs_pts), np.ones(self.n_obs_pts), (self.n_obs_pts,))  # :60-65
+        return self
 
     def _derive(self, u_target=0.5, amp=10.0, sigma=0.1, ctrl_pos=1.0, L=2.0, nx=500):
         self.L, self.nx, self.amp, self.sigma, self.u_target = L, nx, amp, sigma, u_target
@@ -547,13 +583,17 @@ class VecShkadov(VecEnv):
         self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
         self.seed, self.replica_offset = int(seed), 0
         super().__init__(batch, device, dtype)
-        self.action_space = Box(-1.0, 1.0, (n_jets,))
-        self.observation_space = Box(-1.0, 1.0, (self.n_obs * n_jets,))
+        self._make_spaces()
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(self.seed)
         self._init_dev = None
         if self._init_np is not None:
             self._init_dev = self._real(np.ascontiguousarray(self._init_np[:, :self.nx]), (2, self.nx))
+
+    def _make_spaces(self):
+        self.action_space = spaces.box(-1.0, 1.0, (self.n_jets,))               # shkadov.py:96-99
+        self.observation_space = spaces.sym_box(1.0, self.n_obs * self.n_jets)  # :105-110
+        return self
 
     def _derive(self, L0=150.0, n_jets=5, jet_pos=150.0, jet_space=10.0, delta=0.1, t_act=20.0):
         self.L = L0 + jet_space * (n_jets + 2)                           # :32
@@ -627,11 +667,15 @@ class VecSloshing(VecEnv):
         self._derive(L, amp, alpha, g)
         self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
         super().__init__(batch, device, dtype)
-        self.action_space = Box(-1.0, 1.0, (1,))
-        self.observation_space = Box(-1.0, 1.0, (self.n_obs,))
+        self._make_spaces()
         self._init_dev = None
         if self._init_np is not None:
             self._init_dev = self._real(self._init_np, (2, self.nx + 2))
+
+    def _make_spaces(self):
+        self.action_space = spaces.box(-1.0, 1.0, (1,))                         # sloshing.py:73-76
+        self.observation_space = spaces.sym_box(1.0, self.n_obs)                # :81-86
+        return self
 
     def _derive(self, L=2.5, amp=5.0, alpha=0.0005, g=9.81):
         self.L, self.amp, self.alpha, self.g = L, amp, alpha, g

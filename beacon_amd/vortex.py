@@ -7,7 +7,7 @@ import math
 import numpy as np
 
 from .lorenz import _A, _B
-from .vec import Box
+from . import spaces
 
 
 class vortex(object):
@@ -31,8 +31,8 @@ class vortex(object):
         self.mod_min, self.mod_max = 0.0, 0.3
         self.phase_min, self.phase_max = -math.pi, math.pi
         self.x, self.xk, self.fx = np.zeros(4), np.zeros(4), np.zeros(4)
-        self.action_space = Box(-1.0, 1.0, (2,))
-        self.observation_space = Box(-1.0e-4, 1.0e-4, (self.n_obs,))
+        self.action_space = spaces.box(-1.0, 1.0, (2,))
+        self.observation_space = spaces.sym_box(1.0e-4, self.n_obs)
         self.reset_fields()
 
     def _y(self):

@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on a one-GPU box: with --gpus 1, run the process group, barriers, reductions and the packed "
                          "gather of the N > 1 path through the backend all the same (a world of one rank over RCCL)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1 path: the packed gather as a blocking collective between two steps (round 3) instead of on a side "
+                         "stream beside the next step (double-buffered outputs)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; nccl needs one device per rank)")
     ap.add_argument("--L", type=float, default=2.56, help="domain length (nx = 50 L; rayleigh.py:26)")
@@ -201,37 +204,45 @@ def cpu_legs(state0, acts, cfg_kw, seconds=14.0):
 # ------------------------------------------------------------------------------------------------
 # stub env: CPU tensors, same surface (launcher / sharding test on machines without a GPU)
 # ------------------------------------------------------------------------------------------------
-class StubEnv(object):
-    action_is_int = False
+def make_stub_env(batch):
+    """CPU stand-in env: beacon_amd.vec.VecEnv's own host logic (packed, double-buffered outputs, masks) with the three
+    calls that reach the HIP library replaced by tensor operations on CPU tensors."""
+    import numpy as np
+    import torch
+    from beacon_amd.vec import VecEnv
 
-    def __init__(self, batch):
-        import torch
-        from beacon_amd.vec import unpack_outputs, out_layout
-        self.batch, self.obs_dim, self.n_actions, self.n_sgts = batch, 8, 10, 10
-        self.tdtype, self.device = torch.float32, torch.device("cpu")
-        self.nx, self.ny, self.ndt_act, self.kernel_name = 4, 4, 2, "stub"
-        self.out_buf = torch.zeros((out_layout(batch, 8, 4)["bytes"],), dtype=torch.uint8)
-        self.obs, self.rwd, self.status, self.done, self.trunc = unpack_outputs(self.out_buf, batch, 8, self.tdtype)
-        self.sweeps = torch.ones((batch, 2), dtype=torch.int32)
+    class StubEnv(VecEnv):
+        action_is_int = False
 
-    def reset(self):
-        self.obs.zero_()
-        return self.obs, None
+        def __init__(self, batch):
+            self.batch, self.obs_dim, self.n_actions, self.n_sgts = batch, 8, 10, 10
+            self.tdtype, self.device, self.h = torch.float32, torch.device("cpu"), None
+            self.nx, self.ny, self.ndt_act = 4, 4, 2
+            self._alloc_outputs()
+            self.sweeps = torch.ones((batch, 2), dtype=torch.int32)
 
-    def step(self, a, noise=None):
-        self.obs[:] = a[:, :8] * 2
-        self.rwd[:] = a.sum(1)
-        return self.obs, self.rwd, self.done, self.trunc, None
+        kernel_name = "stub"
 
-    def check_status(self):
-        return self.status
+        def _apply_mask(self, mask):
+            self._mask = mask
 
-    def get_counters(self):
-        import numpy as np
-        return np.ones((self.batch, 4), dtype=np.uint64)
+        def _reset(self):
+            self.obs.zero_()
 
-    def close(self):
-        pass
+        def _step(self, a, noise=None):
+            self.obs[:] = a[:, :8] * 2
+            self.rwd[:] = a.sum(1)
+
+        def check_status(self):
+            return self.status
+
+        def get_counters(self):
+            return np.ones((self.batch, 4), dtype=np.uint64)
+
+        def close(self):
+            pass
+
+    return StubEnv(batch)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -310,13 +321,20 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
         acts = torch.as_tensor(head_acts, dtype=env.tdtype, device=dev)
         k = [0]
 
+        sw = []
+
         def st():
             env.step(acts[k[0]]); k[0] += 1
+            if k[0] > W:
+                sw.append(env.sweeps.clone())           # every TIMED step's sweep counts, not only the last one's
         n = acts.shape[0] - W
         ms = timed(env, st, n, warm=W)
         c = env.get_counters()
-        line(name, env, ms, algorithmic_bytes(env.nx, env.ny, env.sweeps.cpu().numpy(), 4 if dtype == "f32" else 8),
-             {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean()), "steps": n, "options": opts, "note": note,
+        esz = 4 if dtype == "f32" else 8
+        alg = float(np.mean([algorithmic_bytes(env.nx, env.ny, x.cpu().numpy(), esz) for x in sw]))
+        line(name, env, ms, alg,
+             {"mean_jacobi_sweeps_per_timestep": float(np.mean([x.float().mean().item() for x in sw])), "steps": n,
+              "options": opts, "note": note,
               "late_stops_last_step": int(c[:, 2].sum()), "repeated_timesteps_last_step": int(c[:, 3].sum())})
         env.close()
 
@@ -429,7 +447,7 @@ def main():
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29751")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))   # two rehearsals on one host must not collide
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         tmo = datetime.timedelta(seconds=args.dist_timeout)
@@ -463,7 +481,7 @@ def main():
 
     def make_env(nrep):
         if args.stub:
-            return StubEnv(nrep)
+            return make_stub_env(nrep)
         e = V.VecRayleigh(nrep, dev, args.dtype, init, L=L, H=H)
         if args.variant >= 0:
             e.set_variant(args.variant)
@@ -471,8 +489,60 @@ def main():
             e.set_sched(args.sched)
         return e
 
+    def sync():
+        if not args.stub:
+            torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        if not args.stub:
+            torch.cuda.synchronize()
+
+    def timed_steps(env, senv, acts, W, K, collective, after_warmup=None):
+        """W untimed warm-up steps, then EXACTLY K timed ones between barrier + synchronize on both sides.  Every step is
+        ONE HIP launch on torch's current stream, bracketed by HIP events on that stream; with `collective` the
+        trainer-facing gather of every step's packed outputs is inside the timed region -- on a side stream behind an
+        event (ShardedVecEnv.step_async: the step after next waits for it before it overwrites the buffer), or with
+        --no-overlap as a blocking collective between two steps."""
+        for k in range(W):
+            senv.step(acts[k], scattered=True)
+        sync()
+        if after_warmup is not None:
+            after_warmup()
+            sync()
+        use_ev = not args.stub
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_ev else []
+        sweeps_all = []
+        pend = None
+        t0 = time.perf_counter()
+        for k in range(K):
+            if use_ev:
+                ev[k][0].record()
+            p = None
+            if collective and senv.overlap:
+                p = senv.step_async(acts[W + k], scattered=True)   # the one HIP launch of this step + its gather (side stream)
+            else:
+                env.step(acts[W + k])                              # the one HIP launch of this step (torch's current stream)
+            if use_ev:
+                ev[k][1].record()
+            sweeps_all.append(env.sweeps.clone())       # tiny device copy, for the roofline accounting
+            if collective and not senv.overlap:
+                senv._gather()                          # --no-overlap: blocking collective between two steps
+            if pend is not None:
+                pend.wait()                             # rank 0 takes delivery of step k - 1 while step k runs
+            pend = p
+        if pend is not None:
+            pend.wait()
+        sync()
+        elapsed = time.perf_counter() - t0
+        env.check_status()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        kern_ms = [s_.elapsed_time(e_) for s_, e_ in ev] if use_ev else [1e3 * elapsed / K] * K
+        return float(tt.item()), kern_ms, sweeps_all
+
     env = make_env(B)
-    senv = ShardedVecEnv(env, always_collective=args.force_dist)
+    senv = ShardedVecEnv(env, always_collective=args.force_dist, overlap=not args.no_overlap)
     # one global action stream, every rank takes the slice of its replicas (weak: a longer stream)
     acts_g = np.random.default_rng(1234).uniform(-1.0, 1.0, (W + K, Bg, env.n_sgts))
     if args.zero_actions:
@@ -480,43 +550,47 @@ def main():
     acts_np = acts_g[:, senv.lo:senv.hi]
     acts = torch.as_tensor(acts_np, dtype=env.tdtype, device=dev)
     senv.reset()
+    saved = {}
 
-    def sync():
-        if not args.stub:
-            torch.cuda.synchronize()
-        if distc:
-            dist.barrier()
-        if not args.stub:
-            torch.cuda.synchronize()
+    def keep_state():          # the CPU legs start from the GPU's state after the warm-up steps
+        if rank == 0 and not args.stub and not args.no_cpu and world == 1:
+            saved["state"] = env.get_state()[:min(os.cpu_count() or 1, B)].cpu().numpy().astype(np.float64)
 
-    for k in range(W):
-        senv.step(acts[k], scattered=True)
-    sync()
-    state_after_warmup = None
-    if rank == 0 and not args.stub and not args.no_cpu and world == 1:
-        state_after_warmup = env.get_state()[:min(os.cpu_count() or 1, B)].cpu().numpy().astype(np.float64)
-        sync()
-    use_ev = not args.stub
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_ev else []
-    sweeps_all, cyc_all = [], []
-    t0 = time.perf_counter()
-    for k in range(K):
-        if use_ev:
-            ev[k][0].record()
-        env.step(acts[W + k])                       # the one HIP launch of this step (torch's current stream)
-        if use_ev:
-            ev[k][1].record()
-        sweeps_all.append(env.sweeps.clone())       # tiny device copy, for the roofline accounting
-        if distc:                                   # trainer-facing gather (one collective), inside the timed region
-            senv._gather()
-    sync()
-    elapsed = time.perf_counter() - t0
-    env.check_status()
+    elapsed, kern_ms, sweeps_all = timed_steps(env, senv, acts, W, K, distc, keep_state)
+    state_after_warmup = saved.get("state")
     cyc = env.get_counters().astype(np.float64)     # of the last step
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if distc:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
+
+    def dist_path_lines():
+        """The headline workload once more through the N > 1 code path on this one GPU: a process group of ONE rank over the
+        backend (nccl = RCCL), barriers and the max-reduction around the timed region, and every step's packed outputs
+        gathered through the backend inside it -- what the driver's 2 / 4 / 8-GPU runs execute per rank, so that the N = 1
+        record shows what that path costs."""
+        import datetime
+        lines = []
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=args.dist_timeout),
+                                device_id=torch.device(dev))
+        try:
+            for overlap in (True, False):
+                e2 = make_env(B)
+                s2 = ShardedVecEnv(e2, always_collective=True, overlap=overlap)
+                s2.reset()
+                t2, k2, sw2 = timed_steps(e2, s2, acts, W, K, True)
+                lines.append({"workload": "headline workload through the N > 1 path: one rank over %s, packed gather %s"
+                                          % (args.backend, "on a side stream beside the next step (double-buffered outputs)"
+                                             if overlap else "as a blocking collective between two steps (--no-overlap)"),
+                              "value": B * K / t2, "unit": "env steps/s", "ms_per_step": 1e3 * t2 / K,
+                              "ms_per_launch": float(np.mean(k2)), "kernel": e2.kernel_name, "dtype": args.dtype,
+                              "steps": K, "warmup": W, "vs_plain_ms_per_step": 1e3 * t2 / K / (1e3 * elapsed / K),
+                              "mean_jacobi_sweeps_per_timestep": float(np.mean([x.float().mean().item() for x in sw2]))})
+                e2.close()
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+        return lines
 
     # N > 1, weak scaling: one more short timed loop with the GLOBAL batch of --batch replicas sharded over the ranks,
     # so that one invocation carries both readings of "batch=512 at 1/2/4/8 GPUs" (same barriers, max over ranks)
@@ -524,28 +598,18 @@ def main():
     if distc and args.scaling == "weak" and not args.no_strong and args.batch % world == 0:
         Bs, Ks, Ws = args.batch // world, min(K, 5), 1
         env_s = make_env(Bs)
-        senv_s = ShardedVecEnv(env_s, always_collective=args.force_dist)
+        senv_s = ShardedVecEnv(env_s, always_collective=args.force_dist, overlap=not args.no_overlap)
         a_s = np.random.default_rng(1234).uniform(-1.0, 1.0, (Ws + Ks, args.batch, env_s.n_sgts))[:, senv_s.lo:senv_s.hi]
         a_s = torch.as_tensor(a_s, dtype=env_s.tdtype, device=dev)
         senv_s.reset()
-        for k in range(Ws):
-            senv_s.step(a_s[k], scattered=True)
-        sync()
-        t0 = time.perf_counter()
-        for k in range(Ks):
-            env_s.step(a_s[Ws + k])
-            senv_s._gather()
-        sync()
-        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        env_s.check_status()
+        t_strong, _, _ = timed_steps(env_s, senv_s, a_s, Ws, Ks, True)
+        ts = torch.tensor([t_strong], dtype=torch.float64, device=dev)
         strong = {"scaling": "strong", "global_batch": args.batch, "replicas_per_gpu": Bs, "steps": Ks, "warmup": Ws,
                   "ms_per_step": 1e3 * float(ts.item()) / Ks, "value": args.batch * Ks / float(ts.item()),
                   "unit": "env steps/s"}
         env_s.close()
 
     if rank == 0:
-        kern_ms = [s.elapsed_time(e) for s, e in ev] if use_ev else [1e3 * elapsed / K] * K
         esz = 4 if args.dtype == "f32" else 8
         sw_np = [s.cpu().numpy() for s in sweeps_all]
         alg = [algorithmic_bytes(env.nx, env.ny, s, esz) for s in sw_np]
@@ -566,7 +630,11 @@ def main():
             roof["traffic"] = tr["value"]
             roof["hbm_measured"] = {"bytes_per_launch": tr["value"], "GB/s": tr["value"] / launch_s / 1e9,
                                     "frac_of_peak": tr["value"] / launch_s / 1e9 / HBM_PEAK_GBS,
-                                    "source": "profiles/" + tr["source"]}
+                                    "source": "profiles/" + tr["source"],
+                                    "measured_in_this_run": False,
+                                    "note": "PMC counters need rocprofv3: bytes per launch are those of the committed profile "
+                                            "(same command, same workload), divided by THIS run's launch time"}
+            roof["traffic_source"] = "profiles/" + tr["source"] + " (committed rocprofv3 --pmc pass; not re-measured by this run)"
         # Poisson phase alone (what north_star's ">= 50 % on the Poisson sweep" refers to): share of the replicas'
         # shader cycles spent inside the Jacobi loop (in-kernel s_memtime, last step) x launch time
         if cyc[:, 1].sum() > 0:
@@ -585,7 +653,13 @@ def main():
         if vi and vi.get("sweeps_per_dispatch"):
             insts = vi["value"] * sweeps_per_launch / vi["sweeps_per_dispatch"]
             binding.update({"achieved": insts / launch_s, "frac": insts / launch_s / VALU_ISSUE_PEAK,
-                            "source": "profiles/" + vi["source"]})
+                            "source": "profiles/" + vi["source"], "measured_in_this_run": False,
+                            "profile_sweeps_per_dispatch": vi["sweeps_per_dispatch"],
+                            "this_run_sweeps_per_launch": sweeps_per_launch,
+                            "note": "SQ_INSTS_VALU of the committed profile, scaled by this run's sweeps per launch over the "
+                                    "profile's, divided by THIS run's launch time"})
+            sys.stderr.write("bench.py: VALU / HBM counters rescaled from profiles/%s (%.4g sweeps per dispatch there, %.4g per "
+                             "launch in this run)\n" % (vi["source"], vi["sweeps_per_dispatch"], sweeps_per_launch))
         roof["binding"] = binding
         metric = "aggregate env steps/sec, rayleigh-v0 batch=%d%s %dx%d" % (args.batch, "/GPU" if args.scaling == "weak" else " global", env.nx, env.ny)
         out = {
@@ -609,8 +683,16 @@ def main():
         if world == 1 and not args.no_cpu and not args.stub:
             out["cpu_baseline"] = cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H))
         if world == 1 and not args.no_secondary and not args.stub:
+            sec = []
+            if not distc:
+                sec = dist_path_lines()
             env.close()
-            out["secondary"] = secondary_lines(dev, acts_np, W, init, (L, H))
+            sec += secondary_lines(dev, acts_np, W, init, (L, H))
+            out["secondary"] = sec
+            for d in sec:      # the figure under the PROVEN stop rule next to the headline
+                if d.get("options") == {"conv_plan": 1} and d.get("dtype") == args.dtype:
+                    out["config"]["proven_stop_rule"] = {"ms_per_step": d["ms_per_launch"], "value": d["value"],
+                                                         "unit": "env steps/s", "note": "conv_plan=1: see `secondary`"}
         print(json.dumps(out), flush=True)
     env.close()
     if distc:

@@ -28,6 +28,12 @@ extern "C" {
 
 #define BCN_API __attribute__((visibility("default")))
 
+/* Bumped whenever the size of a caller-provided buffer or a struct layout changes; bcn_api_version() returns the value
+ * the loaded library was built with, so a caller compiled against an older header can refuse to run.
+ *   4: bcn_get_counters writes BCN_COUNTER_WORDS = 4 words per replica (2 before); bcn_get_counters_n takes the count. */
+#define BCN_API_VERSION 4
+#define BCN_COUNTER_WORDS 4
+
 typedef struct bcn_env_s* bcn_env_t;
 
 enum { BCN_F32 = 0, BCN_F64 = 1 };
@@ -168,8 +174,12 @@ BCN_API int bcn_set_mask(bcn_env_t h, const uint8_t* mask_dev);
 BCN_API int bcn_get_stp(bcn_env_t h, int32_t* buf_host, void* stream);
 BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);
 /* Which kernel variant *_step uses: 0 = generic (any grid, fields in HBM/L2, Jacobi in LDS),
- * 1 = register-resident CDNA4 path where the grid has one (default there; falls back to 0 otherwise):
- * rayleigh 128x64 f32/f64, 50x50 f32/f64, 100x50 / 150x50 / 200x50 / 100x100 f32; mixing 100x100 f32.
+ * 1 = register-resident CDNA4 path where the grid has one (default there; falls back to 0 otherwise).  Built into the
+ * library: rayleigh 128x64 f32/f64, 50x50 f32/f64, 100x50 / 150x50 / 200x50 f32 (one row per lane: ns2d_fast_impl.h);
+ * rayleigh and mixing 100x100 f32/f64 (two rows per lane: ns2d_fast2_impl.h).  Every other grid gets its kernel through
+ * bcn_set_fast_plugin (beacon_amd/jit.py compiles it on demand): one row per lane for rayleigh with ny <= 64, two rows per
+ * lane for 64 < ny <= 128, and for everything else up to ny = 256 (tall grids, grids wider than the strips, mixing below
+ * ny = 64) the hybrid of ns2d_fast4_impl.h (Poisson solve in registers, fields in HBM/L2).  Beyond that: variant 0 only.
  * Results of the two variants agree to rounding (float64: 1e-9).  Returns the variant actually selected. */
 BCN_API int bcn_set_variant(bcn_env_t h, int variant);
 /* Measurement aid (no reference counterpart), uint64[B][4] on the host, per replica, of the last *_step (all chunks):
@@ -178,8 +188,16 @@ BCN_API int bcn_set_variant(bcn_env_t h, int variant);
  *       plan (conv_plan 2 / 3) had skipped -- the plan did not foresee the stop, so an earlier sweep may have passed too,
  *   [3] timesteps (rayleigh) / solves (two-rows-per-lane and tall-grid kernels) that were repeated: a speculative jump that went too
  *       far, or conv_plan 3 repeating a late stop under the proven plan.
- * Zeros for kernels that do not count (generic 2D kernel, 1D envs). */
+ * Zeros for kernels that do not count (generic 2D kernel, 1D envs).
+ * NOTE on [2]/[3] under conv_plan 3 with the speculative jump (spec_start > 0): the jump's FIRST evaluation failing is taken as
+ * proof that no earlier sweep passed, which rests on the observed -- not proven -- monotone decay of the weighted norm; such a
+ * miss would show in neither counter, so zeros in [2] do not by themselves certify that every stop sweep is the reference's
+ * ("verify_conv" checks exactly that, and conv_plan 1 / spec_start 0 are the proven settings).
+ * buf_host must hold batch * BCN_COUNTER_WORDS words; bcn_get_counters_n writes `words_per_replica` words per replica instead
+ * (the first min(words, BCN_COUNTER_WORDS) counters, zeros beyond) for callers built against another header. */
 BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
+BCN_API int bcn_get_counters_n(bcn_env_t h, uint64_t* buf_host, int words_per_replica, void* stream);
+BCN_API int bcn_api_version(void);
 /* Register-resident kernel for a grid that is not built into the library (up to ny = 256; above ny = 128 and for grids wider
  * than the all-in-registers kernels' strips only the Poisson solve is register-resident: csrc/ns2d_fast4_impl.h).  The reference takes any L, H
  * (rayleigh.py:20-27: nx = 50 L, ny = 50 H; mixing.py:20-28: 100 L, 100 H); csrc/jit/ns2d_jit.hip is compiled for ONE

@@ -1896,6 +1896,40 @@ from beacon_amd.envs import packaged_init
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 dev, Bl = "cuda:0", 3
+
+
+def episode(env, acts, G, sharded, rank, stp0, lo=0, hi=None):
+    # one fixed sequence of trainer calls (VERDICT r03 item 1b): staggered episode ends, a single-env reset with a
+    # mask, a masked step, auto-resets; `sharded`: payloads matter on rank 0 only, every rank makes the same calls
+    log = []
+    root = (not sharded) or rank == 0
+    def rec(*t):
+        if root:
+            log.append([x.clone() for x in t if x is not None and torch.is_tensor(x)])
+    o, _ = env.reset(); rec(o)
+    (env.env if sharded else env).set_stp(stp0[lo:hi])
+    for k in range(acts.shape[0]):
+        if k == 2:
+            m = torch.zeros(G, dtype=torch.uint8); m[1::3] = 1
+            o, _ = env.reset(mask=m if root else True); rec(o)
+        if k == 3:
+            m = (torch.arange(G) %% 4 != 0)
+            o, r, d, t, _ = env.step(acts[k] if root else None, mask=m if root else True)
+        else:
+            o, r, d, t, _ = env.step(acts[k] if root else None)
+        rec(o, r, d, t)
+        if k %% 2 == 1:
+            o, _ = env.reset_done(); rec(o)
+    return log
+
+
+def same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert len(x) == len(y)
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+
 rng = np.random.default_rng(5)
 for name in ("rayleigh", "burgers"):
     def make(B):
@@ -1923,6 +1957,22 @@ for name in ("rayleigh", "burgers"):
     else:
         assert all(x[0] is None for x in outs)
     senv.close()
+# staggered resets, masks and auto-reset through the sharded env, gather overlapped (double-buffered outputs)
+G = world * Bl
+acts = torch.as_tensor(rng.uniform(-1, 1, (6, G, 10)), dtype=torch.float32)
+stp0 = np.array([97, 98, 99, 96, 99, 98], dtype=np.int32)
+def make(B):
+    e = V.VecRayleigh(B, dev, "f32", packaged_init("rayleigh")); e.set_ndt_act(10); return e
+for overlap in (False, True):
+    senv = ShardedVecEnv(make(Bl), overlap=overlap)
+    got = episode(senv, acts, G, True, rank, stp0, senv.lo, senv.hi)
+    if rank == 0:
+        ref = make(G)
+        want = episode(ref, acts, G, False, 0, stp0)
+        assert sum(int(x[2].sum()) for x in want if len(x) == 4) >= 5       # episodes did end, at different steps
+        same(got, want)
+        ref.close()
+    senv.close()
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -1937,6 +1987,40 @@ from beacon_amd.dist import ShardedVecEnv
 from beacon_amd.envs import packaged_init
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
+
+
+def episode(env, acts, G, sharded, rank, stp0, lo=0, hi=None):
+    # one fixed sequence of trainer calls (VERDICT r03 item 1b): staggered episode ends, a single-env reset with a
+    # mask, a masked step, auto-resets; `sharded`: payloads matter on rank 0 only, every rank makes the same calls
+    log = []
+    root = (not sharded) or rank == 0
+    def rec(*t):
+        if root:
+            log.append([x.clone() for x in t if x is not None and torch.is_tensor(x)])
+    o, _ = env.reset(); rec(o)
+    (env.env if sharded else env).set_stp(stp0[lo:hi])
+    for k in range(acts.shape[0]):
+        if k == 2:
+            m = torch.zeros(G, dtype=torch.uint8); m[1::3] = 1
+            o, _ = env.reset(mask=m if root else True); rec(o)
+        if k == 3:
+            m = (torch.arange(G) %% 4 != 0)
+            o, r, d, t, _ = env.step(acts[k] if root else None, mask=m if root else True)
+        else:
+            o, r, d, t, _ = env.step(acts[k] if root else None)
+        rec(o, r, d, t)
+        if k %% 2 == 1:
+            o, _ = env.reset_done(); rec(o)
+    return log
+
+
+def same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert len(x) == len(y)
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+
 dev, B = "cuda:0", 6
 rng = np.random.default_rng(5)
 for name in ("rayleigh", "burgers"):
@@ -1958,6 +2042,33 @@ for name in ("rayleigh", "burgers"):
         o, r, d, t, _ = outs[k]
         assert o.is_cuda and o.shape == obs.shape and torch.equal(o, obs) and torch.equal(r, rwd) and torch.equal(d, done), (name, k)
     assert int(senv.gather_status().max()) == 0
+    ref.close(); senv.close()
+# the gather on a side stream beside the next step (double-buffered outputs): step_async, results taken one step late
+def make():
+    e = V.VecRayleigh(B, dev, "f32", packaged_init("rayleigh")); e.set_ndt_act(10); return e
+acts = torch.as_tensor(rng.uniform(-1, 1, (6, B, 10)), dtype=torch.float32, device=dev)
+senv = ShardedVecEnv(make(), always_collective=True, overlap=True)
+assert senv.overlap and senv._side is not None and len(senv.env.out_bufs) == 2
+ref = make(); ref.reset(); senv.reset()
+pend, outs = [], []
+for k in range(6):
+    pend.append(senv.step_async(acts[k]))
+    if len(pend) == 2:
+        outs.append([x.clone() for x in pend.pop(0).wait()[:4]])
+outs.append([x.clone() for x in pend.pop(0).wait()[:4]])
+for k in range(6):
+    o, r, d, t, _ = ref.step(acts[k])
+    assert torch.equal(outs[k][0], o) and torch.equal(outs[k][1], r) and torch.equal(outs[k][2], d), k
+ref.close(); senv.close()
+# masks, single-env resets and auto-reset through the sharded env == the plain env, bit for bit
+stp0 = np.array([97, 98, 99, 96, 99, 98], dtype=np.int32)
+for overlap in (False, True):
+    senv = ShardedVecEnv(make(), always_collective=True, overlap=overlap)
+    got = episode(senv, acts, B, True, 0, stp0)
+    ref = make()
+    want = episode(ref, acts, B, False, 0, stp0)
+    assert sum(int(x[2].sum()) for x in want if len(x) == 4) >= 5
+    same(got, want)
     ref.close(); senv.close()
 torch.cuda.synchronize()
 dist.barrier()

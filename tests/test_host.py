@@ -161,9 +161,9 @@ class Env:                                               # CPU stand-in with the
         self.out_buf = torch.zeros((out_layout(B, 3, 4)["bytes"],), dtype=torch.uint8)
         self.obs, self.rwd, self.status, self.done, self.trunc = unpack_outputs(self.out_buf, B, 3, torch.float32)
         self.gen = torch.Generator()
-    def reset(self):
+    def reset(self, mask=None):
         self.obs.fill_(-1.0); return self.obs, None
-    def step(self, a, noise=None):
+    def step(self, a, noise=None, mask=None):
         self.obs[:] = a + 1; self.rwd[:] = a.sum(1); self.done.fill_(1)
         return self.obs, self.rwd, self.done, self.trunc, None
 
@@ -190,6 +190,105 @@ def test_replica_sharding_collectives_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29713", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
+_WORKER2 = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch
+import torch.distributed as dist
+from beacon_amd.dist import ShardedVecEnv
+from cpu_env import CpuVecEnv
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+B, NA = 6, 4                                          # replicas per rank, episode length
+G = B * world
+gen = torch.Generator().manual_seed(3)
+acts = torch.rand((14, G, 3), generator=gen)
+stp0 = torch.tensor([0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3], dtype=torch.int32)   # staggered episode ends
+
+
+def script(env, sharded):
+    # one fixed sequence of trainer calls; `sharded`: the env is a ShardedVecEnv (payloads matter on rank 0 only)
+    log = []
+    root = (not sharded) or rank == 0
+    def rec(*t):
+        if root:
+            log.append([x.clone() for x in t if x is not None and torch.is_tensor(x)])
+    o, _ = env.reset(); rec(o)
+    if sharded:                                        # staggered episode ends: set behind the reset on both sides
+        env.env.stp[:] = stp0[env.lo:env.hi]
+    else:
+        env.stp[:] = stp0
+    for k in range(12):
+        if k == 5:                                     # the trainer resets single envs (rayleigh.py:89-99)
+            m = torch.zeros(G, dtype=torch.uint8); m[[1, 4, 7, 10]] = 1
+            o, _ = env.reset(mask=m if root else True); rec(o)
+        if k == 8:                                     # a masked step: rows of skipped replicas keep their values
+            m = (torch.arange(G) %% 3 != 0)
+            o, r, d, t, _ = env.step(acts[k] if root else None, mask=m if root else True)
+        else:
+            o, r, d, t, _ = env.step(acts[k] if root else None)
+        rec(o, r, d, t)
+        if k %% 2 == 1:
+            o, _ = env.reset_done(); rec(o)
+    return log
+
+
+# reference: ONE process stepping the global batch
+ref = CpuVecEnv(G, n_act=NA)
+ref_log = script(ref, False)
+assert sum(int(x[2].sum()) for x in ref_log if len(x) == 4) >= 20      # episodes did end, at different steps
+for overlap in (False, True):
+    loc = CpuVecEnv(B, n_act=NA)
+    senv = ShardedVecEnv(loc, overlap=overlap)
+    assert senv.overlap == overlap and (len(loc.out_bufs) == 2) == overlap
+    got = script(senv, True)
+    if rank == 0:
+        assert len(got) == len(ref_log)
+        for a, b in zip(got, ref_log):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), (overlap, x, y)
+    else:
+        assert got == []
+# step_async: two gathers in flight, results consumed one step late, buffers rotate
+loc = CpuVecEnv(B, n_act=NA); senv = ShardedVecEnv(loc, overlap=True)
+ref = CpuVecEnv(G, n_act=NA); ref.reset(); senv.reset()
+pend, outs = [], []
+for k in range(6):
+    pend.append(senv.step_async(acts[k] if rank == 0 else None))
+    if len(pend) == 2:
+        outs.append([None if x is None else x.clone() for x in pend.pop(0).wait()[:4]])
+outs.append([None if x is None else x.clone() for x in pend.pop(0).wait()[:4]])
+for k in range(6):
+    o, r, d, t, _ = ref.step(acts[k])
+    if rank == 0:
+        assert torch.equal(outs[k][0], o) and torch.equal(outs[k][1], r) and torch.equal(outs[k][2], d)
+    else:
+        assert outs[k][0] is None
+assert (senv.gather_status() is not None) == (rank == 0)
+senv.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_env_masks_auto_reset_and_overlapped_gather_gloo_world2(tmp_path):
+    """ShardedVecEnv.reset(mask) / step(mask=) / reset_done() and the double-buffered, asynchronous
+    gather (step_async) over two processes -- every output of a 12-step script with staggered episode ends, single-env
+    resets, a masked step and auto-resets equals, bit for bit, ONE process stepping the global batch."""
+    script = tmp_path / "worker2.py"
+    script.write_text(_WORKER2 % (ROOT, ROOT))
+    s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
@@ -292,3 +391,56 @@ def test_lorenz_vortex_render_and_dump(tmp_path, monkeypatch):
     env.dump(str(tmp_path / "vortex.dat"))
     d = np.loadtxt(tmp_path / "vortex.dat")
     assert d.shape == (1 + env.ndt_act, 7) and np.allclose(d[-1, 5:], [env.kmod, env.kphase], rtol=1e-5)
+
+
+_SPACES_CHECK = r"""
+import sys, numpy as np
+import gymnasium
+from gymnasium import spaces as gsp
+from beacon_amd import spaces, vec, lorenz, vortex
+assert spaces.have_gymnasium()
+def mk(cls, *a, **k):
+    c = getattr(vec, cls)
+    return c._derive(c.__new__(c), *a, **k)._make_spaces()
+r = mk("VecRayleigh", 2.56, 1.28)
+assert isinstance(r.action_space, gsp.Box) and isinstance(r.observation_space, gsp.Box)
+assert r.action_space.low == -0.75 and r.action_space.high == 0.75 and r.action_space.shape == (10,)   # rayleigh.py:75-78
+assert r.action_space.dtype == np.float32 and r.observation_space.shape == (384,)
+assert np.array_equal(r.observation_space.high, np.ones(384)) and np.array_equal(r.observation_space.low, -np.ones(384))
+m = mk("VecMixing")
+assert isinstance(m.action_space, gsp.Discrete) and m.action_space.n == 4 and m.observation_space.shape == (192,)
+b = mk("VecBurgers")
+assert np.array_equal(b.observation_space.low, np.zeros(5)) and np.array_equal(b.observation_space.high, np.ones(5))
+assert b.action_space.shape == (1,) and b.action_space.low == -1.0
+s = mk("VecShkadov", n_jets=10)
+assert s.action_space.shape == (10,) and s.observation_space.shape == (100,)
+sl = mk("VecSloshing")
+assert sl.observation_space.shape == (100,) and isinstance(sl.action_space, gsp.Box)
+lz = lorenz()
+assert isinstance(lz.action_space, gsp.Discrete) and lz.action_space.n == 3 and isinstance(lz.observation_space, gsp.Box)
+vx = vortex()
+assert isinstance(vx.action_space, gsp.Box) and vx.action_space.shape == (2,)
+assert np.array_equal(vx.observation_space.high, np.ones(vx.n_obs) * 1.0e-4)
+print("spaces ok")
+"""
+
+
+def test_mirrors_carry_real_gymnasium_spaces_when_gymnasium_is_importable():
+    """rayleigh.py:75-86, mixing.py:61-70, ...: with a `gymnasium` on sys.path (here the capture stand-in package, the only
+    one this container has) the mirrors' spaces are that package's Box / Discrete, built with the reference's arguments;
+    without it, beacon_amd.spaces' own stand-ins with the same attributes."""
+    stubs = os.path.join(ROOT, "oracle", "capture", "stubs")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, stubs, os.environ.get("PYTHONPATH", "")]))
+    out = subprocess.run([sys.executable, "-c", _SPACES_CHECK], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "spaces ok" in out.stdout, out.stderr[-2000:]
+    from beacon_amd import spaces
+    try:
+        import gymnasium  # noqa: F401
+    except ImportError:
+        assert not spaces.have_gymnasium()
+        bx = spaces.box(-0.75, 0.75, (10,))
+        assert isinstance(bx, spaces.Box) and bx.shape == (10,) and bx.low.dtype == np.float32 and bx.high[3] == np.float32(0.75)
+        sb = spaces.sym_box(1.0, 7)
+        assert sb.shape == (7,) and np.array_equal(sb.low, -np.ones(7, np.float32)) and sb.contains(np.zeros(7))
+        d = spaces.discrete(4)
+        assert d.n == 4 and d.contains(3) and not d.contains(4) and 0 <= d.sample(np.random.default_rng(0)) < 4
