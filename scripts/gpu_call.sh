@@ -1,0 +1,37 @@
+#!/bin/bash
+# One gpurun call of the build -> measure loop (run on the GPU box from the repo root): the -m gpu tests with the error
+# log behind the tolerances, the bench line, and a kernel trace of the N > 1 path with one rank.  A step that was killed
+# (exit code >= 124) ends the call: nothing else touches the GPU behind it.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+step() { # name, timeout, command...
+  local name=$1 tmo=$2; shift 2
+  echo "== $name" | tee -a $OUT/steps.log
+  timeout -k 10 $tmo "$@" > $OUT/$name.log 2> $OUT/$name.err
+  local rc=$?
+  echo "== $name rc=$rc" | tee -a $OUT/steps.log
+  if [ $rc -ge 124 ]; then echo "killed: stop" | tee -a $OUT/steps.log; exit $rc; fi
+  return $rc
+}
+export BEACON_NO_BUILD=1
+for what in "$@"; do
+  case $what in
+    tests)   BEACON_ERRLOG=$OUT/errlog.jsonl step tests 900 python3 -m pytest tests -m gpu -q -x ;;
+    tests_all) BEACON_ERRLOG=$OUT/errlog.jsonl step tests 900 python3 -m pytest tests -m gpu -q ;;
+    dist)    step tests_dist 600 python3 -m pytest tests -m gpu -q -k "rccl or gloo or masked" ;;
+    bench)   step bench 600 python3 bench.py --steps 20 --warmup 5 ;;
+    benchq)  step benchq 600 python3 bench.py --steps 20 --warmup 5 --no-cpu --no-secondary ;;
+    fdist)   step fdist 600 python3 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu --no-secondary
+             step fdist_noov 600 python3 bench.py --gpus 1 --force-dist --no-overlap --steps 20 --warmup 5 --no-cpu --no-secondary ;;
+    trace_fdist)
+      cd /tmp && export TMPDIR=/tmp
+      step trace_fdist 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fdist -o run -- python3 $ROOT/bench.py --gpus 1 --force-dist --steps 10 --warmup 2 --no-cpu --no-secondary
+      find $OUT/trace_fdist -name '*kernel_stats.csv' -exec cp {} $OUT/trace_fdist_kernel_stats.csv \;
+      find $OUT/trace_fdist -name '*kernel_trace.csv' -exec cp {} $OUT/trace_fdist_kernel_trace.csv \;
+      rm -rf $OUT/trace_fdist
+      cd $ROOT ;;
+    *) echo "unknown step $what" ;;
+  esac
+done
+exit 0

@@ -31,7 +31,18 @@ def dev2ref(state):
 
 
 def maxdiff(a, b):
-    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    """max |a - b|.  With BEACON_ERRLOG=<file> every evaluation is appended there as a JSON line (test id, line of the
+    assertion, value): scripts/tolerance_report.py turns that log into the table the float32 tolerances are set from
+    (tolerance <= 10 x the measured error: VERDICT r03 item 2a)."""
+    d = float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    log = os.environ.get("BEACON_ERRLOG")
+    if log:
+        import json
+        import sys
+        with open(log, "a") as fh:
+            fh.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0].split("::")[-1],
+                                 "line": sys._getframe(1).f_lineno, "pos": sys._getframe(1).f_lasti, "err": d}) + "\n")
+    return d
 
 
 # ---------------------------------------------------------------------------------------------
@@ -70,7 +81,7 @@ def test_rayleigh_default_vs_golden(dtype, ftol, otol, swtol, variant):
         o = obs.cpu().numpy()
         assert maxdiff(o[0], o[1]) == 0 and maxdiff(o[0], o[2]) == 0      # replicas are independent and equal
         assert maxdiff(o[0], g["step%d_obs" % k]) <= otol
-        assert abs(float(rwd[0]) - float(g["step%d_rwd" % k])) <= 50 * otol
+        assert maxdiff(float(rwd[0]), float(g["step%d_rwd" % k])) <= 50 * otol
         fields = dev2ref(env.get_state())[0]
         for i, F in enumerate("uvpT"):
             tol = ftol * (20 if F == "p" else 1)       # p accumulates phi over all timesteps
@@ -131,7 +142,7 @@ def test_rayleigh_batch_vs_oracle_f64(variant):
         for b, o in enumerate(oracles):
             ob, rw, dn, tr, _ = o.step(acts[k, b].tolist())
             assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL
-            assert abs(float(rwd[b]) - rw) <= 1e-8
+            assert maxdiff(float(rwd[b]), rw) <= 1e-8
             assert maxdiff(st[b][3], o.S) <= F64_TOL and maxdiff(st[b][0], o.u) <= F64_TOL
             assert np.max(np.abs(sw[b] - o.itp)) <= 1       # a replica at the threshold may take +-1
     env.close()
@@ -239,7 +250,7 @@ def test_rayleigh_100x100_fast2_vs_oracle_and_generic():
             for i, F in enumerate("uvpT"):
                 assert maxdiff(st[b][i], o.st[i]) <= 5e-5 * (50 if F == "p" else 1), (k, b, F)
             assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5
-            assert abs(float(rwd[b]) - rw) <= 2e-4
+            assert maxdiff(float(rwd[b]), rw) <= 2e-4
             assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(4, 0.04 * o.itp)), (sw[b], o.itp)
         fast.append((raw.clone(), sw.copy()))
     assert env.set_variant(0) == 0
@@ -283,7 +294,7 @@ def test_ns2d_generic_other_grids_vs_oracle_f64():
             ob, rw, _, _, _ = o.step(acts[k, b].tolist())
             for i, F in enumerate("uvpT"):
                 assert maxdiff(st[b][i], o.st[i]) <= F64_TOL * (50 if F == "p" else 1), (k, b, F)
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and abs(float(rwd[b]) - rw) <= 1e-8
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and maxdiff(float(rwd[b]), rw) <= 1e-8
             assert np.max(np.abs(sw[b] - o.itp)) <= 1
     env.close()
 
@@ -302,7 +313,7 @@ def test_ns2d_generic_other_grids_vs_oracle_f64():
         ob, rw, _, _, _ = o.step(int(a[b]))
         for i, F in enumerate("uvpC"):
             assert maxdiff(st[b][i], o.st[i]) <= F64_TOL * (50 if F == "p" else 1), (b, F)
-        assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and abs(float(rwd[b]) - rw) <= 1e-9
+        assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and maxdiff(float(rwd[b]), rw) <= 1e-9
         assert np.max(np.abs(sw[b] - o.itp)) <= 1
     env.close()
 
@@ -386,15 +397,15 @@ def test_rayleigh_bench_dispatch_vs_oracle_and_reference(dtype, ftol, swtol):
     for b in range(NREP):
         for i, F in enumerate("uvpT"):
             assert maxdiff(st[b][i], ost[b][i]) <= ftol * (pf if F == "p" else 1), (b, F)
-        assert maxdiff(o[b], oobs[b]) <= ftol and abs(r[b] - orwd[b]) <= max(1e-8, 2 * ftol)
-        assert abs(int(sw[b].sum()) - int(osw[b])) <= max(swtol, 0.002 * osw[b] if dtype == "f32" else 0), (b, sw[b].sum(), osw[b])
+        assert maxdiff(o[b], oobs[b]) <= ftol and maxdiff(r[b], orwd[b]) <= max(1e-8, 2 * ftol)
+        assert maxdiff(int(sw[b].sum()), int(osw[b])) <= max(swtol, 0.002 * osw[b] if dtype == "f32" else 0), (b, sw[b].sum(), osw[b])
     for b in (0, 1):                      # the reference itself
         g = golden("rayleigh_128x64_step%d" % b)
         assert np.array_equal(g["action"], acts[0, b])
         for i, F in enumerate("uvpT"):
             assert maxdiff(st[b][i], g[F]) <= ftol * (pf if F == "p" else 1), (b, F)
         # the capture steps from loaded fields without reset()'s get_obs: only the newest history slot is comparable
-        assert maxdiff(o[b][-96:], g["obs"][-96:]) <= ftol and abs(r[b] - float(g["rwd"])) <= max(1e-8, 2 * ftol)
+        assert maxdiff(o[b][-96:], g["obs"][-96:]) <= ftol and maxdiff(r[b], float(g["rwd"])) <= max(1e-8, 2 * ftol)
         assert np.max(np.abs(sw[b] - g["itp"])) <= swtol, (b, np.max(np.abs(sw[b] - g["itp"])))
     env.close()
 
@@ -454,7 +465,7 @@ def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler(dtype, tol, swrel):
         ob, rw, _, _, _ = o.step(int(a[b]))
         for i, F in enumerate("uvpC"):
             assert maxdiff(st[b][i], o.st[i]) <= tol * ((5 if dtype == "f32" else 50) if F == "p" else 1), (b, F)
-        assert maxdiff(x[0][b].cpu().numpy(), ob) <= tol and abs(float(x[1][b]) - rw) <= max(1e-9, 0.05 * tol)
+        assert maxdiff(x[0][b].cpu().numpy(), ob) <= tol and maxdiff(float(x[1][b]), rw) <= max(1e-9, 0.05 * tol)
         assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(1 if dtype == "f64" else 3, swrel * o.itp)), b
         assert torch.equal(x[0][b], x[0][b + 4])          # same action -> same replica, whatever CU ran it
 
@@ -917,7 +928,7 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
         for i, F in enumerate("uvpT"):
             assert maxdiff(out[1][2][b][i], o.st[i]) <= tol * (50 if F == "p" else 1), (b, F)
         n = 3 * env.nx_obs_pts * env.ny_obs_pts
-        assert maxdiff(out[1][0][b][-n:], ob[-n:]) <= tol and abs(out[1][1][b] - rw) <= max(1e-8, 4 * tol)
+        assert maxdiff(out[1][0][b][-n:], ob[-n:]) <= tol and maxdiff(out[1][1][b], rw) <= max(1e-8, 4 * tol)
         assert np.all(np.abs(out[1][3][b] - o.itp) <= (1 if dtype == "f64" else np.maximum(3, 0.02 * o.itp)))
     assert maxdiff(out[1][2], out[0][2]) <= 50 * tol
     env.close()
@@ -947,7 +958,7 @@ def test_jit_grid_mixing_vs_oracle(L, H):
         ob, rw, _, _, _ = o.step(int(a[b]))
         for i, F in enumerate("uvpC"):
             assert maxdiff(st[b][i], o.st[i]) <= 2e-4 * (50 if F == "p" else 1), (b, F)
-        assert abs(float(rwd[b]) - rw) <= 1e-5
+        assert maxdiff(float(rwd[b]), rw) <= 1e-5
         assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(3, 0.02 * o.itp)), b
     env.close()
 
@@ -985,7 +996,7 @@ def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
             ob, rw, _, _, _ = o.step(acts[k, b].tolist())
             for i, F in enumerate("uvpT"):
                 assert maxdiff(st[b][i], o.st[i]) <= 5e-5 * (50 if F == "p" else 1), (k, b, F)
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5 and abs(float(rwd[b]) - rw) <= 2e-4
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5 and maxdiff(float(rwd[b]), rw) <= 2e-4
             assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(4, 0.04 * o.itp)), (sw[b], o.itp)
     env.close()
 
@@ -1019,7 +1030,7 @@ def test_rayleigh_odd_configs_generic_vs_oracle_f64(L, H, n_sgts, ra):
             ob, rw, _, _, _ = o.step(acts[k, b].tolist())
             for i, F in enumerate("uvpT"):
                 assert maxdiff(st[b][i], o.st[i]) <= F64_TOL * (50 if F == "p" else 1), (k, b, F)
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and abs(float(rwd[b]) - rw) <= 1e-8
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= F64_TOL and maxdiff(float(rwd[b]), rw) <= 1e-8
             assert np.max(np.abs(sw[b] - o.itp)) <= 1
     env.close()
 
@@ -1090,7 +1101,7 @@ def test_mixing_from_rest_vs_golden(act, dtype, tol, swrel, variant):
         t = tol * (50 if F == "p" else 1)
         assert maxdiff(st[i], g["step0_" + F]) <= t, (F, maxdiff(st[i], g["step0_" + F]))
     assert maxdiff(obs.cpu().numpy()[0], g["step0_obs"]) <= tol
-    assert abs(float(rwd[0]) - float(g["step0_rwd"])) <= tol
+    assert maxdiff(float(rwd[0]), float(g["step0_rwd"])) <= tol
     assert env.kernel_name == ("ns2d_fast2_step" if variant else "ns2d_generic_step")
     env.close()
 
@@ -1238,7 +1249,7 @@ def test_burgers_vs_golden(dtype, tol):
         obs, rwd, done, trunc, _ = env.step(a, nz)
         errs.append(maxdiff(obs[0].cpu().numpy(), g["s0_obs"][k]))
         assert errs[-1] <= tol
-        assert abs(float(rwd[0]) - g["s0_rwd"][k]) <= tol
+        assert maxdiff(float(rwd[0]), g["s0_rwd"][k]) <= tol
         if k < n1:
             assert maxdiff(obs[1].cpu().numpy(), g["s1_obs"][k]) <= tol
         if k == n1 - 1:
@@ -1318,7 +1329,7 @@ def test_burgers_nx512_vs_oracle_and_mirror():
         obs, rwd, _, _, _ = env.step(a, nz)
         for b, o in enumerate(ors):
             ob, rw, _, _, _ = o.step([a[b]], nz[b])
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= 1e-12 and abs(float(rwd[b]) - rw) <= 1e-12
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= 1e-12 and maxdiff(float(rwd[b]), rw) <= 1e-12
     env.close()
     g = golden("burgers")
     e = E.burgers()
@@ -1354,7 +1365,7 @@ def test_shkadov_vs_golden(tag, kw, init, dtype, tol0):
         nz = np.tile(g[tag + "_noise"][k], (2, 1))
         obs, rwd, done, trunc, _ = env.step(a, nz)
         assert maxdiff(obs[0].cpu().numpy(), g[tag + "_obs"][k]) <= tol, k
-        assert abs(float(rwd[0]) - g[tag + "_rwd"][k]) <= tol
+        assert maxdiff(float(rwd[0]), g[tag + "_rwd"][k]) <= tol
         assert not bool(done[0])
     st = env.get_state().cpu().numpy()[1]
     tol = tol0 * 1.45 ** n
@@ -1414,7 +1425,7 @@ def test_sloshing_vs_golden(dtype, tol):
     for k in range(len(g["actions"])):
         obs, rwd, done, trunc, _ = env.step(np.tile(g["actions"][k], 2))
         assert maxdiff(obs[1].cpu().numpy(), g["obs"][k]) <= tol, k
-        assert abs(float(rwd[1]) - g["rwd"][k]) <= tol
+        assert maxdiff(float(rwd[1]), g["rwd"][k]) <= tol
     st = env.get_state().cpu().numpy()[0]
     for i, f in enumerate(("h", "q", "rhsh", "rhsq")):
         assert maxdiff(st[i], g[f]) <= tol * (1 if i < 2 else 100)
@@ -1452,7 +1463,7 @@ def test_sloshing_other_lengths_vs_oracle_f64(L, nsteps):
         st = env.get_state().cpu().numpy()
         for b, o in enumerate(oracles):
             ob, rw, dn, _, _ = o.step([acts[k, b]])
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= 1e-12 and abs(float(rwd[b]) - rw) <= 1e-12
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= 1e-12 and maxdiff(float(rwd[b]), rw) <= 1e-12
             assert maxdiff(st[b][0], o.h) <= 1e-12 and maxdiff(st[b][1], o.q) <= 1e-12
             assert bool(done[b]) == bool(dn)
     env.close()
@@ -1470,7 +1481,7 @@ def test_env1d_float64_bit_identical_to_oracle():
         obs, rwd, _, _, _ = env.step(np.array([a]), np.array([n]))
         ob, rw, _, _, _ = o.step([a], n)
         assert np.array_equal(env.get_state().cpu().numpy()[0, 0], o.u) and np.array_equal(obs[0].cpu().numpy(), ob)
-        assert abs(float(rwd[0]) - rw) <= 1e-13
+        assert maxdiff(float(rwd[0]), rw) <= 1e-13
     env.close()
     init = E.packaged_init("sloshing")
     env, o = V.VecSloshing(1, DEV, "f64", init), O.sloshing(init_fields=init)
@@ -1481,7 +1492,7 @@ def test_env1d_float64_bit_identical_to_oracle():
         ob, rw, _, _, _ = o.step([a])
         st = env.get_state().cpu().numpy()[0]
         assert np.array_equal(st[0], o.h) and np.array_equal(st[1], o.q) and np.array_equal(obs[0].cpu().numpy(), ob)
-        assert abs(float(rwd[0]) - rw) <= 1e-13
+        assert maxdiff(float(rwd[0]), rw) <= 1e-13
     env.close()
     init = E.packaged_init("shkadov")
     env, o = V.VecShkadov(1, DEV, "f64", init), O.shkadov(init_fields=init)
@@ -1493,7 +1504,7 @@ def test_env1d_float64_bit_identical_to_oracle():
         ob, rw, _, _, _ = o.step(a.tolist(), nz)
         st = env.get_state().cpu().numpy()[0]
         assert np.array_equal(st[0], o.h) and np.array_equal(st[1], o.q) and np.array_equal(obs[0].cpu().numpy(), ob)
-        assert abs(float(rwd[0]) - rw) <= 1e-13
+        assert maxdiff(float(rwd[0]), rw) <= 1e-13
     env.close()
 
 
@@ -1728,7 +1739,7 @@ def test_shkadov_separable_mirror():
     for r in range(3):
         for j in range(5):
             obs, rwd, done, trunc, _ = e.step(g["actions"][r].tolist())
-            assert maxdiff(obs, g["obs"][k]) <= 1e-12 and abs(rwd - g["rwd"][k]) <= 1e-14
+            assert maxdiff(obs, g["obs"][k]) <= 1e-12 and maxdiff(rwd, g["rwd"][k]) <= 1e-14
             assert [done, trunc] == g["done"][k].tolist() and e.stp == g["stp"][k]
             k += 1
     assert maxdiff(e.h, g["h"]) <= 1e-12
