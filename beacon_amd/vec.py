@@ -599,6 +599,7 @@ class VecShkadov(VecEnv):
         self.L = L0 + jet_space * (n_jets + 2)                           # :32
         self.nx = int(5 * self.L)                                        # :33
         self.dt, self.dt_act, self.t_act = 0.001, 0.05, t_act
+        self.n_warmup_ref = int(200.0 / self.dt_act)                     # :36,62 t_warmup = 200 -> 4000 action steps (init.py)
         self.sigma, self.delta, self.n_jets, self.jet_amp = 5.0e-4, delta, n_jets, 5.0
         self.eps, self.blowup_rwd, self.h_max = 1.0e-8, -1.0, 5.0
         self.dx = float(self.L / self.nx)                                # :56

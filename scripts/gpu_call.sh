@@ -19,6 +19,8 @@ for what in "$@"; do
   case $what in
     tests)   BEACON_ERRLOG=$OUT/errlog.jsonl step tests 900 python3 -m pytest tests -m gpu -q -x ;;
     tests_all) BEACON_ERRLOG=$OUT/errlog.jsonl step tests 900 python3 -m pytest tests -m gpu -q ;;
+    newtests) BEACON_ERRLOG=$OUT/errlog_new.jsonl step newtests 900 python3 -m pytest tests -m gpu -q -k "episode_drift or developed_film or episode_statistics or shkadov_vs_golden" ;;
+    drift) BEACON_ERRLOG=$OUT/errlog_drift.jsonl step drift 900 python3 -m pytest tests -m gpu -q -k "episode_drift" ;;
     dist)    step tests_dist 600 python3 -m pytest tests -m gpu -q -k "rccl or gloo or masked" ;;
     bench)   step bench 600 python3 bench.py --steps 20 --warmup 5 ;;
     benchq)  step benchq 600 python3 bench.py --steps 20 --warmup 5 --no-cpu --no-secondary ;;
