@@ -396,11 +396,13 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
       for (;;) {
         BCN_F4_SWEEP(true)
         n_eval++;
+        // the reference tests the sweep count FIRST: a solve that reaches sweep itmax + 1 overflows even if that sweep passes
+        // (rayleigh.py:451-454, in front of the loop condition)
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
         if (!(err > A.tol)) {
           if (skip_left > 0) status |= BCN_ST_PLAN;
           break;
         }
-        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
         int n = 0;
         if (skip_left > 0) {
           skip_left--;

@@ -81,6 +81,13 @@ def choose(nx, ny, f64, kind):
             rl = nx - (nw - 1) * r
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
                 continue
+            # float64: strips of equal width only (one instantiation of the body), and at most 16 columns per lane.  The
+            # two-body float64 kernel of 110x64 (strips of 14 and 12 columns, u, v in LDS, T in the global scratch) stopped
+            # converging in its third timestep after a semantically neutral reordering of two tests in the Jacobi loop
+            # (round 4; column 99, the narrow strip's first one; root cause not found): such grids take the hybrid kernel
+            # of ns2d_fast4_impl.h (below) instead
+            if f64 and (rl != r or r > 16):
+                continue
             for gf in ((0,) if not f64 else (2, 1)):
                 if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
@@ -94,7 +101,8 @@ def choose(nx, ny, f64, kind):
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx or (only and nw != only):
                 continue
             exch = 2 * nw * 4 * 64 + 160
-            lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
+            padc = (r - rl) * (ny + 2) + 16 if rl != r else 0      # float32: one body for every strip (Fast2Geom::PADC)
+            lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2) + padc) * esz
             if lds <= LDS_BYTES:
                 return {"rows": 2, "R": r, "gf": 1 if f64 else 0, "nw": nw}
     return _choose4(nx, ny, f64)

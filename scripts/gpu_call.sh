@@ -21,6 +21,9 @@ for what in "$@"; do
     tests_all) BEACON_ERRLOG=$OUT/errlog.jsonl step tests 900 python3 -m pytest tests -m gpu -q ;;
     newtests) BEACON_ERRLOG=$OUT/errlog_new.jsonl step newtests 900 python3 -m pytest tests -m gpu -q -k "episode_drift or developed_film or episode_statistics or shkadov_vs_golden" ;;
     drift) BEACON_ERRLOG=$OUT/errlog_drift.jsonl step drift 900 python3 -m pytest tests -m gpu -q -k "episode_drift" ;;
+    mix)     step mix 600 python3 scripts/mix_counters.py f32 ;;
+    mixtests) step mixtests 900 python3 -m pytest tests -m gpu -q -k "mixing or fast2 or jit_grid or jit_grids or stop_rule or conv_plan or 100x100 or speculative" ;;
+    smoke)   step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke()" ;;
     dist)    step tests_dist 600 python3 -m pytest tests -m gpu -q -k "rccl or gloo or masked" ;;
     bench)   step bench 600 python3 bench.py --steps 20 --warmup 5 ;;
     benchq)  step benchq 600 python3 bench.py --steps 20 --warmup 5 --no-cpu --no-secondary ;;

@@ -22,6 +22,42 @@ if torch.cuda.is_available():
     from beacon_amd import vec as V
 
 F64_TOL = 1e-9       # f64 kernels vs f64 reference (absolute, fields are O(1))
+
+# float32 tolerances: every one is <= 10 x the error MEASURED on that workload in round 4 (BEACON_ERRLOG=... pytest, then
+# scripts/tolerance_report.py; the measured maxima are quoted next to each entry as "# m: u v p S obs rwd").  All are absolute
+# errors against the float64 reference / oracle on fields of size O(1) (|T| <= 1.25, |u|, |v| <~ 0.3 for rayleigh, <= 1 for
+# mixing; rewards: the Nusselt number, O(2-5), for rayleigh, a mean of |C - 0.25| for mixing).
+def f32tol(u, v, p, S, obs, rwd):
+    return dict(u=u, v=v, p=p, T=S, C=S, obs=obs, rwd=rwd)
+
+
+F32 = {
+    # 50x50, 2 full steps + a repeat: generic m: 6.9e-7 8.6e-7 4.0e-7 1.8e-6 1.3e-6 2.6e-6; register-resident m: 3.1e-7 3.9e-7 2.1e-7 9.0e-7 6.8e-7 4.0e-6
+    ("ray_default", 0): f32tol(6e-6, 6e-6, 4e-6, 1.5e-5, 1e-5, 2.5e-5),
+    ("ray_default", 1): f32tol(3e-6, 3e-6, 2e-6, 8e-6, 6e-6, 3e-5),
+    # 128x64, 5 timesteps from the synthetic state (velocities still tiny): m: 1.5e-8 3.7e-8 2.8e-7 2.3e-7 1.2e-7 / 6.6e-9 4.4e-9 2.0e-7 2.7e-7 7.4e-8
+    ("ray_128x64", 0): f32tol(1.5e-7, 3e-7, 2.5e-6, 2e-6, 1e-6, None),
+    ("ray_128x64", 1): f32tol(6e-8, 4e-8, 2e-6, 2.5e-6, 7e-7, None),
+    # 100x100 rayleigh (two rows per lane), 2 x 12 timesteps: m: 7.7e-9 7.7e-9 1.5e-7 3.1e-7 2.7e-7 3.2e-6
+    "ray_100x100": f32tol(7e-8, 7e-8, 1.5e-6, 3e-6, 2.5e-6, 3e-5),
+    # wide domains (100 / 150 / 200 x 50), 2 x 10 timesteps: m: 4.9e-9 4.3e-9 4.2e-8 3.1e-7 2.1e-7 3.7e-6
+    "ray_wide": f32tol(5e-8, 5e-8, 4e-7, 3e-6, 2e-6, 3.5e-5),
+    # on-demand grids, 30 timesteps; by kernel: one row per lane m: 6.4e-9 7.6e-9 1.5e-7 3.8e-7; two rows m: 1.4e-7 1.0e-7 9.8e-7 3.7e-7;
+    # Poisson-only in registers (tall / wide) m: 5.4e-7 4.1e-7 7.4e-6 5.4e-7; observations 3.5e-7, rewards 6.2e-6 over all of them
+    ("ray_jit", 1): f32tol(6e-8, 7e-8, 1.5e-6, 3.8e-6, 3.5e-6, 6e-5),
+    ("ray_jit", 2): f32tol(1.4e-6, 1e-6, 9e-6, 3.7e-6, 3.5e-6, 6e-5),
+    ("ray_jit", 4): f32tol(5e-6, 4e-6, 7e-5, 5e-6, 3.5e-6, 6e-5),
+    # mixing 100x100 from rest, 3 timesteps: m: 1.1e-7 1.2e-7 3.9e-7 2.7e-7 9.2e-8 3.2e-8
+    "mix_rest": f32tol(1e-6, 1e-6, 3.5e-6, 2.5e-6, 9e-7, 3e-7),
+    # mixing B = 512, one full step (250 timesteps): m: 1.3e-6 2.2e-6 1.1e-5 2.5e-6 1.2e-6 2.1e-8
+    "mix_bench": f32tol(1.3e-5, 2e-5, 1e-4, 2.5e-5, 1e-5, 2e-7),
+    # on-demand mixing grids, 40 timesteps: two rows per lane m: 1.2e-7 1.2e-7 3.0e-7 8.3e-7 - 4.9e-8; 100x200 m: 7.6e-7 4.8e-7 1.4e-5 9.5e-7 - 1.6e-8;
+    # 200x100 m: 5.4e-8 5.3e-8 1.7e-7 8.1e-7 - 3.6e-8
+    ("mix_jit", 2): f32tol(1.2e-6, 1.2e-6, 3e-6, 8e-6, None, 4.5e-7),
+    ("mix_jit", "100x130"): f32tol(1.2e-6, 1.2e-6, 3e-6, 8e-6, None, 4.5e-7),
+    ("mix_jit", "100x200"): f32tol(7e-6, 4.5e-6, 1.4e-4, 9e-6, None, 4.5e-7),
+    ("mix_jit", "200x100"): f32tol(5e-7, 5e-7, 1.7e-6, 8e-6, None, 4.5e-7),
+}
 DEV = "cuda:0"
 
 
@@ -62,10 +98,11 @@ def _variant(env, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("dtype,ftol,otol,swtol", [("f64", F64_TOL, F64_TOL, 0), ("f32", 2e-4, 2e-4, 2)])
-def test_rayleigh_default_vs_golden(dtype, ftol, otol, swtol, variant):
+@pytest.mark.parametrize("dtype,swtol", [("f64", 0), ("f32", 2)])
+def test_rayleigh_default_vs_golden(dtype, swtol, variant):
     """50x50, shipped init state, 2 action steps (400 timesteps) + a=None repeat.
-    f32 tolerance: fields/obs 2e-4 absolute (|T|<=1.25, |u|,|v|<~0.3), sweeps within +-2."""
+    f32 tolerances: F32["ray_default", variant] (measured errors x <= 10), sweeps within +-2."""
+    tol = F32["ray_default", variant] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 20 * F64_TOL, F64_TOL, F64_TOL, 50 * F64_TOL)
     g = golden("rayleigh_default")
     B = 3
     env = V.VecRayleigh(B, DEV, dtype, _ray_init(g))
@@ -80,12 +117,11 @@ def test_rayleigh_default_vs_golden(dtype, ftol, otol, swtol, variant):
         assert not st.any()
         o = obs.cpu().numpy()
         assert maxdiff(o[0], o[1]) == 0 and maxdiff(o[0], o[2]) == 0      # replicas are independent and equal
-        assert maxdiff(o[0], g["step%d_obs" % k]) <= otol
-        assert maxdiff(float(rwd[0]), float(g["step%d_rwd" % k])) <= 50 * otol
+        assert maxdiff(o[0], g["step%d_obs" % k]) <= tol["obs"]
+        assert maxdiff(float(rwd[0]), float(g["step%d_rwd" % k])) <= tol["rwd"]
         fields = dev2ref(env.get_state())[0]
         for i, F in enumerate("uvpT"):
-            tol = ftol * (20 if F == "p" else 1)       # p accumulates phi over all timesteps
-            assert maxdiff(fields[i], g["step%d_%s" % (k, F)]) <= tol, (k, F)
+            assert maxdiff(fields[i], g["step%d_%s" % (k, F)]) <= tol[F], (k, F)
         sw = env.sweeps.cpu().numpy()[0]
         assert np.max(np.abs(sw - g["itp"][k])) <= swtol
         assert maxdiff(env.actions_norm.cpu().numpy()[0], g["step%d_a_norm" % k]) <= (1e-15 if dtype == "f64" else 1e-7)
@@ -94,9 +130,10 @@ def test_rayleigh_default_vs_golden(dtype, ftol, otol, swtol, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("dtype,tol", [("f64", F64_TOL), ("f32", 5e-5)])
-def test_rayleigh_128x64_vs_golden(dtype, tol, variant):
-    """BASELINE grid, seeded synthetic state, 5 timesteps (first Poisson solve: 5375 sweeps)."""
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rayleigh_128x64_vs_golden(dtype, variant):
+    """BASELINE grid, seeded synthetic state, 5 timesteps (first Poisson solve: 5375 sweeps).  f32: F32["ray_128x64", variant]."""
+    tol = F32["ray_128x64", variant] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, None)
     g = golden("rayleigh_128x64")
     env = V.VecRayleigh(2, DEV, dtype, None, L=2.56, H=1.28)
     env.set_ndt_act(5)
@@ -111,9 +148,9 @@ def test_rayleigh_128x64_vs_golden(dtype, tol, variant):
     assert np.all(np.abs(sw - ref_sw) <= (0 if dtype == "f64" else np.maximum(3, 0.01 * ref_sw)))
     fields = dev2ref(env.get_state())[0]
     for i, F in enumerate("uvpT"):
-        assert maxdiff(fields[i], g["step0_" + F]) <= tol * (50 if F == "p" else 1), F
+        assert maxdiff(fields[i], g["step0_" + F]) <= tol[F], F
     # obs: the history slots before this step hold zeros, the last slot the new samples
-    assert maxdiff(obs.cpu().numpy()[0][-96:], g["step0_obs"][-96:]) <= tol
+    assert maxdiff(obs.cpu().numpy()[0][-96:], g["step0_obs"][-96:]) <= tol["obs"]
     # bottom ghost cells right of the last segment are never written (rayleigh.py:199-202)
     assert maxdiff(fields[3][121:129, 0], g["T0"][121:129, 0]) == 0
     env.close()
@@ -212,7 +249,7 @@ def test_rayleigh_fast_identical_replicas_are_bit_identical(cfg, dtype):
 def test_rayleigh_100x100_fast2_vs_oracle_and_generic():
     """ns2d_fast2 (two rows per lane, uneven column strips) in its rayleigh instantiation: L = H = 2
     -> 100x100, f32, seeded synthetic start, 2 x 12 timesteps.  Against the f64 oracle per replica
-    (5e-5, p 50x looser as above), against the generic kernel, and replicas with identical inputs
+    (F32["ray_100x100"]: measured errors x <= 10), against the generic kernel, and replicas with identical inputs
     must stay bit-identical (hand-written DPP).  Sweep counts within max(4, 4 %): the stop test
     looks at increments of ~1e-6 on a phi of O(0.1), so float32 rounding moves the crossing a little
     (a start with grid-scale noise in the velocities moves it by tens of percent: phi is O(1) there
@@ -248,9 +285,9 @@ def test_rayleigh_100x100_fast2_vs_oracle_and_generic():
         for b, o in enumerate(oracles):
             ob, rw, _, _, _ = o.step(acts[k, b].tolist())
             for i, F in enumerate("uvpT"):
-                assert maxdiff(st[b][i], o.st[i]) <= 5e-5 * (50 if F == "p" else 1), (k, b, F)
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5
-            assert maxdiff(float(rwd[b]), rw) <= 2e-4
+                assert maxdiff(st[b][i], o.st[i]) <= F32["ray_100x100"][F], (k, b, F)
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= F32["ray_100x100"]["obs"]
+            assert maxdiff(float(rwd[b]), rw) <= F32["ray_100x100"]["rwd"]
             assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(4, 0.04 * o.itp)), (sw[b], o.itp)
         fast.append((raw.clone(), sw.copy()))
     assert env.set_variant(0) == 0
@@ -260,8 +297,8 @@ def test_rayleigh_100x100_fast2_vs_oracle_and_generic():
         env.step(acts[k])
         assert env.kernel_name == "ns2d_generic_step"
         raw = env.get_state()
-        for i, F in enumerate("uvpT"):
-            assert float((raw[:, i] - fast[k][0][:, i]).abs().max()) <= 5e-5 * (50 if F == "p" else 1), (k, F)
+        for i, F in enumerate("uvpT"):      # two float32 kernels, ghost cells included (measured: p 4.6e-6)
+            assert maxdiff(raw[:, i].cpu().numpy(), fast[k][0][:, i].cpu().numpy()) <= (3e-5 if F == "p" else 2 * F32["ray_100x100"][F]), (k, F)
         assert np.all(np.abs(env.sweeps.cpu().numpy() - fast[k][1]) <= np.maximum(4, 0.04 * fast[k][1]))
     env.close()
 
@@ -499,12 +536,12 @@ def test_rayleigh_bench_dispatch_scheduler_is_bit_exact(dtype):
     assert float((a[3][:, 2] - b[3][:, 2]).abs().max()) < (1e-4 if dtype == "f32" else 1e-12)
 
 
-@pytest.mark.parametrize("dtype,tol,swrel", [("f32", 2e-5, 0.02), ("f64", F64_TOL, 0.0)])
-def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler(dtype, tol, swrel):
+@pytest.mark.parametrize("dtype,swrel", [("f32", 0.02), ("f64", 0.0)])
+def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler(dtype, swrel):
     """mixing-v0 at BASELINE configs[4]'s batch: B=512, 100x100, one full 250-timestep step from rest through
     `ns2d_fast2_sched` (256 persistent workgroups): replicas 0..3 (actions 0..3) against the float64 C oracle
-    (float32 tolerance from scripts/f32_errors.py -- measured u, v, C 2.5e-6, p 1.1e-5, observations 1.2e-6, at most two
-    sweeps' difference in a timestep: 2e-5, p 1e-4, sweeps within 3 or 2 %), and the whole batch bit for bit against the
+    (float32: F32["mix_bench"] -- measured u, v, C 2.5e-6, p 1.1e-5, observations 1.2e-6, rewards 2e-8, at most two
+    sweeps' difference in a timestep; sweeps within 3 or 2 %), and the whole batch bit for bit against the
     unscheduled launch."""
     B = 512
     a = (np.arange(B) % 4).astype(np.int64)
@@ -529,9 +566,10 @@ def test_mixing_bench_dispatch_b512_vs_oracle_and_scheduler(dtype, tol, swrel):
         o = O.mixing()
         o.reset()
         ob, rw, _, _, _ = o.step(int(a[b]))
+        tol = F32["mix_bench"] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, 1e-9)
         for i, F in enumerate("uvpC"):
-            assert maxdiff(st[b][i], o.st[i]) <= tol * ((5 if dtype == "f32" else 50) if F == "p" else 1), (b, F)
-        assert maxdiff(x[0][b].cpu().numpy(), ob) <= tol and maxdiff(float(x[1][b]), rw) <= max(1e-9, 0.05 * tol)
+            assert maxdiff(st[b][i], o.st[i]) <= tol[F], (b, F)
+        assert maxdiff(x[0][b].cpu().numpy(), ob) <= tol["obs"] and maxdiff(float(x[1][b]), rw) <= tol["rwd"]
         assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(1 if dtype == "f64" else 3, swrel * o.itp)), b
         assert torch.equal(x[0][b], x[0][b + 4])          # same action -> same replica, whatever CU ran it
 
@@ -983,7 +1021,9 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
         if variant == 1:
             from beacon_amd import jit
             rows = jit.choose(env.nx, env.ny, dtype == "f64", 0)["rows"]
-            assert rows == (4 if env.ny > 128 or env.nx > 208 else 2 if env.ny > 64 else 1)
+            # (float64 with strips of unequal width -- 110x64 -- takes the hybrid kernel: beacon_amd/jit.py)
+            want = 4 if env.ny > 128 or env.nx > 208 else 2 if env.ny > 64 else 1
+            assert rows == (4 if (dtype == "f64" and (env.nx, env.ny) == (110, 64)) else want)
             assert env.kernel_name == {1: "ns2d_fast_step", 2: "ns2d_fast2_step", 4: "ns2d_fast4_step"}[rows]
     for b in range(B):
         o = O.rayleigh(init=False, L=L, H=H)
@@ -991,12 +1031,14 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
         o.reset_fields()
         o.st[:4] = st0
         ob, rw, _, _, _ = o.step(acts[b].tolist())
+        t = F32["ray_jit", rows] if dtype == "f32" else f32tol(tol, tol, 50 * tol, tol, tol, max(1e-8, 4 * tol))
         for i, F in enumerate("uvpT"):
-            assert maxdiff(out[1][2][b][i], o.st[i]) <= tol * (50 if F == "p" else 1), (b, F)
+            assert maxdiff(out[1][2][b][i], o.st[i]) <= t[F], (b, F)
         n = 3 * env.nx_obs_pts * env.ny_obs_pts
-        assert maxdiff(out[1][0][b][-n:], ob[-n:]) <= tol and maxdiff(out[1][1][b], rw) <= max(1e-8, 4 * tol)
+        assert maxdiff(out[1][0][b][-n:], ob[-n:]) <= t["obs"] and maxdiff(out[1][1][b], rw) <= t["rwd"]
         assert np.all(np.abs(out[1][3][b] - o.itp) <= (1 if dtype == "f64" else np.maximum(3, 0.02 * o.itp)))
-    assert maxdiff(out[1][2], out[0][2]) <= 50 * tol
+    for i, F in enumerate("uvpT"):          # the generic kernel on the same inputs: both within the tolerance of the oracle
+        assert maxdiff(out[1][2][:, i], out[0][2][:, i]) <= (2 * F32["ray_jit", rows][F] if dtype == "f32" else 50 * tol), F
     env.close()
 
 
@@ -1022,9 +1064,10 @@ def test_jit_grid_mixing_vs_oracle(L, H):
         o.cfg.ndt_act = 40
         o.reset()
         ob, rw, _, _, _ = o.step(int(a[b]))
+        t = F32["mix_jit", "%dx%d" % (env.nx, env.ny) if (env.ny > 128 or env.nx > 128) else 2]
         for i, F in enumerate("uvpC"):
-            assert maxdiff(st[b][i], o.st[i]) <= 2e-4 * (50 if F == "p" else 1), (b, F)
-        assert maxdiff(float(rwd[b]), rw) <= 1e-5
+            assert maxdiff(st[b][i], o.st[i]) <= t[F], (b, F)
+        assert maxdiff(float(rwd[b]), rw) <= t["rwd"]
         assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(3, 0.02 * o.itp)), b
     env.close()
 
@@ -1032,7 +1075,7 @@ def test_jit_grid_mixing_vs_oracle(L, H):
 @pytest.mark.parametrize("L,nx", [(2.0, 100), (3.0, 150), (4.0, 200)])
 def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
     """Register-resident instantiations for the reference's other natural aspect ratios (nx = 50 L, ny = 50):
-    float32, smooth synthetic start, 2 x 10 timesteps, against the float64 oracle (5e-5; p 50x looser) and with
+    float32, smooth synthetic start, 2 x 10 timesteps, against the float64 oracle (F32["ray_wide"]) and with
     identical replicas bit-identical; the sweep counts within max(4, 4 %) as for the 100x100 test."""
     ny = 50
     rng = np.random.default_rng(17)
@@ -1061,8 +1104,8 @@ def test_rayleigh_wide_domains_fast_vs_oracle(L, nx):
         for b, o in enumerate(oracles):
             ob, rw, _, _, _ = o.step(acts[k, b].tolist())
             for i, F in enumerate("uvpT"):
-                assert maxdiff(st[b][i], o.st[i]) <= 5e-5 * (50 if F == "p" else 1), (k, b, F)
-            assert maxdiff(obs[b].cpu().numpy(), ob) <= 5e-5 and maxdiff(float(rwd[b]), rw) <= 2e-4
+                assert maxdiff(st[b][i], o.st[i]) <= F32["ray_wide"][F], (k, b, F)
+            assert maxdiff(obs[b].cpu().numpy(), ob) <= F32["ray_wide"]["obs"] and maxdiff(float(rwd[b]), rw) <= F32["ray_wide"]["rwd"]
             assert np.all(np.abs(sw[b] - o.itp) <= np.maximum(4, 0.04 * o.itp)), (sw[b], o.itp)
     env.close()
 
@@ -1142,14 +1185,14 @@ def test_rayleigh_single_env_mirror():
 # ---------------------------------------------------------------------------------------------
 # mixing
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype,tol,swrel", [("f64", F64_TOL, 0.0), ("f32", 2e-4, 0.02)])
+@pytest.mark.parametrize("dtype,swrel", [("f64", 0.0), ("f32", 0.02)])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_mixing_from_rest_vs_golden(act, dtype, tol, swrel, variant):
+def test_mixing_from_rest_vs_golden(act, dtype, swrel, variant):
     """100x100 from rest, 3 timesteps; the first Poisson solve takes 2466 sweeps; generic kernel and two-rows-per-lane
     kernel (float32: fields in LDS; float64: fields in a global scratch, rhs in LDS).
-    f32: sweep counts within 2 %, fields 2e-4 (p: 1e-2, it is a sum of three O(1) phi fields
-    each converged only to tol=1e-4 on the increment norm)."""
+    f32: sweep counts within 2 %, fields F32["mix_rest"] (measured errors x <= 10)."""
+    tol = F32["mix_rest"] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, F64_TOL)
     g = golden("mixing_a%d" % act)
     env = V.VecMixing(2, DEV, dtype)
     env.set_ndt_act(3)
@@ -1164,10 +1207,9 @@ def test_mixing_from_rest_vs_golden(act, dtype, tol, swrel, variant):
     assert np.all(np.abs(sw - g["itp"][0]) <= np.maximum(1 if dtype == "f64" else 3, swrel * g["itp"][0])), sw
     st = dev2ref(env.get_state())[0]
     for i, F in enumerate("uvpC"):
-        t = tol * (50 if F == "p" else 1)
-        assert maxdiff(st[i], g["step0_" + F]) <= t, (F, maxdiff(st[i], g["step0_" + F]))
-    assert maxdiff(obs.cpu().numpy()[0], g["step0_obs"]) <= tol
-    assert maxdiff(float(rwd[0]), float(g["step0_rwd"])) <= tol
+        assert maxdiff(st[i], g["step0_" + F]) <= tol[F], F
+    assert maxdiff(obs.cpu().numpy()[0], g["step0_obs"]) <= tol["obs"]
+    assert maxdiff(float(rwd[0]), float(g["step0_rwd"])) <= tol["rwd"]
     assert env.kernel_name == ("ns2d_fast2_step" if variant else "ns2d_generic_step")
     env.close()
 
@@ -1302,7 +1344,9 @@ def test_burgers_vs_golden(dtype, tol):
     (measured 4e-6) and at most 3 steps above 5e-5 (measured: one peak of 4-6e-5 at step 78, with the two-reciprocal
     and the one-reciprocal form of the limiter alike); 1e-3 on the full field after 12400 timesteps (the van Leer
     ratio amplifies rounding at the downstream shocks)."""
-    ftol = tol if dtype == "f64" else 1e-3
+    ftol = tol if dtype == "f64" else 1e-3        # full field after 12 400 timesteps: measured 1.8e-4
+    ftol1 = tol if dtype == "f64" else 3e-5       # ... after 1 550 timesteps (second replica): measured 3.3e-6
+    rtol = tol if dtype == "f64" else 2e-5        # rewards: measured 2.0e-6
     errs = []
     g = golden("burgers")
     env = V.VecBurgers(2, DEV, dtype)
@@ -1315,13 +1359,13 @@ def test_burgers_vs_golden(dtype, tol):
         obs, rwd, done, trunc, _ = env.step(a, nz)
         errs.append(maxdiff(obs[0].cpu().numpy(), g["s0_obs"][k]))
         assert errs[-1] <= tol
-        assert maxdiff(float(rwd[0]), g["s0_rwd"][k]) <= tol
+        assert maxdiff(float(rwd[0]), g["s0_rwd"][k]) <= rtol
         if k < n1:
             assert maxdiff(obs[1].cpu().numpy(), g["s1_obs"][k]) <= tol
         if k == n1 - 1:
             st = env.get_state().cpu().numpy()[1]
             for i, f in enumerate(("u", "up", "upp")):
-                assert maxdiff(st[i], g["s1_" + f]) <= ftol
+                assert maxdiff(st[i], g["s1_" + f]) <= ftol1
     assert bool(done[0]) and bool(trunc[0])              # 200th step ends the episode
     if dtype == "f32":
         assert np.mean(errs) <= 1e-5 and int((np.array(errs) > 5e-5).sum()) <= 3, (np.mean(errs), np.max(errs))
@@ -1595,11 +1639,12 @@ def test_sloshing_vs_golden(dtype, tol):
     assert maxdiff(obs.cpu().numpy()[0], g["reset_obs"]) <= (0 if dtype == "f64" else 1e-7)
     for k in range(len(g["actions"])):
         obs, rwd, done, trunc, _ = env.step(np.tile(g["actions"][k], 2))
-        assert maxdiff(obs[1].cpu().numpy(), g["obs"][k]) <= tol, k
-        assert maxdiff(float(rwd[1]), g["rwd"][k]) <= tol
+        assert maxdiff(obs[1].cpu().numpy(), g["obs"][k]) <= tol, k                    # f32 measured 7.6e-6
+        assert maxdiff(float(rwd[1]), g["rwd"][k]) <= (tol if dtype == "f64" else 2.5e-7)  # f32 measured 2.9e-8
     st = env.get_state().cpu().numpy()[0]
+    ftol = (tol, tol, 100 * tol, 100 * tol) if dtype == "f64" else (1.5e-5, 5e-5, 1.5e-3, 5e-3)   # f32 measured 1.7e-6 7.2e-6 1.7e-4 6.2e-4
     for i, f in enumerate(("h", "q", "rhsh", "rhsq")):
-        assert maxdiff(st[i], g[f]) <= tol * (1 if i < 2 else 100)
+        assert maxdiff(st[i], g[f]) <= ftol[i]
     env.close()
     # warm-up from rest with the reference's excitation signal (sloshing/init.py)
     env = V.VecSloshing(1, DEV, dtype, None)
@@ -1609,7 +1654,8 @@ def test_sloshing_vs_golden(dtype, tol):
         env.step(np.array([env.signal(t, env.dt_act)]))
         t += env.dt_act
     st = env.get_state().cpu().numpy()[0]
-    assert maxdiff(st[0], g["warm_h"]) <= tol and maxdiff(st[1], g["warm_q"]) <= tol
+    wtol = (tol, tol) if dtype == "f64" else (6e-6, 3.5e-5)                              # f32 measured 6.2e-7, 3.8e-6
+    assert maxdiff(st[0], g["warm_h"]) <= wtol[0] and maxdiff(st[1], g["warm_q"]) <= wtol[1]
     env.close()
 
 
