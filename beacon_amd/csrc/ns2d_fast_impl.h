@@ -582,6 +582,38 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #endif
 #undef BCN_OWN_PRED
     // ---- boundary conditions of T (rayleigh.py:180-202, the T part) on the transported field --------------
+    // TREG (T in the global scratch, GF == 2): every thread loads its own row of T once (one coalesced load per column, all
+    // issued before the first use) and the ghost cells are WRITTEN from those registers by the lanes / waves at the walls --
+    // the same expressions on the same values as the strided read-modify-write loops below, without their two rounds of
+    // global-load latency in front of the buoyancy term
+    constexpr bool TREG = GF == 2 && KIND == 0;
+    real Tr[TREG ? R : 1];
+    if constexpr (TREG) {
+#pragma unroll
+      for (int k = 0; k < R; k++) Tr[k] = Tl[(i0 + k) * SY + j];
+      if (active) {   // (wave-uniform branches)
+        if (w == 0) Tl[0 * SY + j] = Tr[0];
+        if (w == NW - 1) Tl[(NX + 1) * SY + j] = Tr[R - 1];
+      }
+      // top and bottom ghost rows: the wall rows' values (lanes NY - 1 and 0) are broadcast, lane k < R stores column k of the
+      // strip -- one store instruction per ghost row, no lane-divergent block
+      {
+        real gt = 0, gb = 0;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          const real tt = read_lane(Tr[k], NY - 1), tb = read_lane(Tr[k], 0);
+          gt = (lane == k) ? 2 * A.Tc - tt : gt;
+          gb = (lane == k) ? tb : gb;
+        }
+        const int ii = i0 + (lane < R ? lane : 0);
+        const int sg = (ii - 1) / A.nx_sgts;
+        const real sa = sact[sg < A.n_sgts ? sg : 0];
+        if (lane < R) {
+          Tl[ii * SY + NY + 1] = gt;
+          if (sg < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sa) - gb;
+        }
+      }
+    } else {
     for (int jj = 1 + tid; jj <= NY; jj += NT) {
       Tl[0 * SY + jj] = Tl[1 * SY + jj];
       Tl[(NX + 1) * SY + jj] = Tl[NX * SY + jj];
@@ -591,10 +623,11 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const int k = (ii - 1) / A.nx_sgts;
       if (k < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sact[k]) - Tl[ii * SY + 1];
     }
+    }
     // ---- buoyancy: v* = v + dt (X + T) (rayleigh.py:405) ----------------------------------------------------
 #pragma unroll
     for (int k = 0; k < R; k++) {
-      const real buoy = (KIND == 0) ? Tl[(i0 + k) * SY + j] : real(0);
+      const real buoy = (KIND == 0) ? (TREG ? Tr[TREG ? k : 0] : Tl[(i0 + k) * SY + j]) : real(0);
       vs[k] = (j >= 2 && active) ? Vl[(i0 + k) * SY + j] + dt * (vx[k] + buoy) : real(0);   // (the old v: re-read, not kept)
     }
     BCN_PH(0)
@@ -1050,11 +1083,25 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     //      boundary conditions and the p exchange of the NEXT timestep of this unit ------------------------------
     {
       real Ac[R];
+      // TREG: the thread's row of T plus the column to its east in ONE round of loads (the neighbouring strip's first column,
+      // or the east ghost the boundary conditions stored); the north value from the lane above, the top ghost computed
+      real Tx[TREG ? R + 1 : 1];
+      if constexpr (TREG) {
+#pragma unroll
+        for (int k = 0; k <= R; k++) Tx[k] = Tl[(i0 + k) * SY + j];
+      }
 #pragma unroll
       for (int k = 0; k < R; k++) {
         const int c = (i0 + k) * SY + j;
         const real uE = Ul[c + SY], uW = Ul[c], vN = Vl[c + 1], vS = Vl[c];
-        const real T0 = Tl[c], TE = Tl[c + SY], TN = Tl[c + 1];
+        real T0, TE, TN;
+        if constexpr (TREG) {
+          T0 = Tx[TREG ? k : 0]; TE = Tx[TREG ? k + 1 : 0];
+          TN = from_above(real(0), T0);
+          TN = (lane == NY - 1) ? 2 * A.Tc - T0 : TN;      // the top ghost (rayleigh.py:188), as the boundary conditions stored it
+        } else {
+          T0 = Tl[c]; TE = Tl[c + SY]; TN = Tl[c + 1];
+        }
         const real expl = A.ksc * ((TE - 2 * T0) * rdx2 + (TN - 2 * T0) * rdy2) -
                           (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
                           (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;

@@ -2,7 +2,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 from beacon_amd import vec as V
 from conftest import ref_to_dev
-L, H, B = 2.2, 1.28, 2
+L, H, B = float(os.environ.get("DBG_L", "2.2")), float(os.environ.get("DBG_H", "1.28")), 2
 NDT = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 env = V.VecRayleigh(B, "cuda:0", "f64", None, L=L, H=H); env.set_ndt_act(NDT)
 for a in sys.argv[2:]:
@@ -22,3 +22,7 @@ for f, name in enumerate("uvpT"):
     j, i = np.unravel_index(d.argmax(), d.shape)
     cols = np.nonzero(d.max(axis=0) > 1e-9)[0]
     print(name, "max diff %.3e at i=%d j=%d; columns with diff > 1e-9: %s" % (d.max(), i, j, (cols.min(), cols.max(), len(cols)) if len(cols) else None))
+d = np.abs(out[1][2] - out[0][2])
+print("p: columns differing:", np.nonzero(d.max(axis=0) > 1e-9)[0].tolist())
+print("p: rows differing:", np.nonzero(d.max(axis=1) > 1e-9)[0].tolist())
+print("p diff at row 1:", np.round(d[1, :20], 4).tolist())

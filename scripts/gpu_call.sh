@@ -24,6 +24,8 @@ for what in "$@"; do
     mix)     step mix 600 python3 scripts/mix_counters.py f32 ;;
     mixtests) step mixtests 900 python3 -m pytest tests -m gpu -q -k "mixing or fast2 or jit_grid or jit_grids or stop_rule or conv_plan or 100x100 or speculative" ;;
     smoke)   step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke()" ;;
+    f64t)    step f64tests 900 python3 -m pytest tests -m gpu -q -k "f64 or float64 or init_generation or identical"
+             step kstat64 600 python3 scripts/kstat.py f64 6 ;;
     dist)    step tests_dist 600 python3 -m pytest tests -m gpu -q -k "rccl or gloo or masked" ;;
     bench)   step bench 600 python3 bench.py --steps 20 --warmup 5 ;;
     benchq)  step benchq 600 python3 bench.py --steps 20 --warmup 5 --no-cpu --no-secondary ;;
