@@ -48,15 +48,9 @@ struct Fast2Geom {
   static constexpr int SY = NY + 2;
   static constexpr int SX = NX + 2;
   static constexpr int SZ = SX * SY;
-  // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 64 | sact 64 | red 32 | U V S | PADC
+  // LDS map (elements): exchange [2][NW][2 sides][2 rows][64] | errp 64 | sact 64 | red 32 | U V S
   static constexpr int EXCH = 2 * NW * 4 * 64;
-  // ONE body for every wave (fields in LDS): the last wave runs the R-column body too, its columns RL .. R-1 are dummies
-  // (never stored, zero rhs, outside the norm) whose unguarded LDS reads run past the arrays -- U into V, V into S, S into
-  // the PADC elements behind it.  Half the code of the two-body form (one instantiation per strip width): the kernel has
-  // to stay inside the instruction cache.
-  static constexpr bool ONE = GF == 0 && RL != R;
-  static constexpr int PADC = ONE ? (R - RL) * SY + 16 : 0;
-  static constexpr size_t lds_elems() { return GF ? (size_t)EXCH + 160 + 2 * (size_t)R * NT : (size_t)EXCH + 160 + 3 * (size_t)SZ + PADC; }
+  static constexpr size_t lds_elems() { return GF ? (size_t)EXCH + 160 + 2 * (size_t)R * NT : (size_t)EXCH + 160 + 3 * (size_t)SZ; }
   static constexpr size_t scratch_elems() { return GF ? 3 * (size_t)SZ + 16 : 0; }   // + 16: the transport wave's sink
 };
 
@@ -212,11 +206,6 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   const bool active = lane < LH;
   constexpr bool ODD = (NY & 1) != 0;
   const bool act1 = active && !(ODD && lane == LH - 1);   // the upper row of the pair exists (odd ny: not in the last lane)
-  // single-body form (G::ONE, RW == R): in the last wave only the columns k < RL exist (colok); its wall column is RL - 1
-  constexpr int RL = G::RL;
-  constexpr bool ONE = G::ONE && RW == R;
-  const bool lastw = ONE && w == NW - 1;
-  auto colok = [&](const int k) -> bool { return !(ONE && k >= RL && lastw); };
   const int la = active ? lane : 0;          // lanes past the top row pair shadow lane 0 (never write)
   int j0 = 2 * la + 1;                       // rows j0 (a = 0) and j0 + 1 (a = 1); GF: laundered once per timestep (below)
   const int i0 = w * R + 1;
@@ -225,23 +214,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   real* __restrict__ gv = A.v + off;
   real* __restrict__ gp = A.p + off;
   real* __restrict__ gS = A.S + off;
-  // exchange buffer [2 buffers][NW][64 lanes][west: rows a = 0, 1 | east: rows a = 0, 1]: a sweep publishes its strip's two edge
-  // columns with ONE 128-bit store per lane and fetches each neighbour's facing column with ONE 64-bit load (was four 32-bit
-  // stores and four loads: every LDS instruction next to the sweep's barrier costs 30-50 cycles of issue)
-  typedef real rv4 __attribute__((ext_vector_type(4)));
-  typedef real rv2 __attribute__((ext_vector_type(2)));
-  auto exq = [&](int buf, int wave) -> real* { return exch + ((buf * NW + wave) * 64 + lane) * 4; };
-  auto ex_put = [&](int buf, real w0, real w1, real e0, real e1) {
-    rv4 v = {w0, w1, e0, e1};
-    *reinterpret_cast<rv4*>(exq(buf, w)) = v;
-  };
-  auto ex_put_east = [&](int buf, real e0, real e1) {     // (the p exchange of the predictor: the east column only)
-    rv2 v = {e0, e1};
-    *reinterpret_cast<rv2*>(exq(buf, w) + 2) = v;
-  };
-  auto ex_get = [&](int buf, int wave, int side, real& r0, real& r1) {
-    const rv2 v = *reinterpret_cast<const rv2*>(exq(buf, wave) + 2 * side);
-    r0 = v.x; r1 = v.y;
+  auto ex = [&](int buf, int wave, int side, int a) -> real* {
+    return exch + (((buf * NW + wave) * 2 + side) * 2 + a) * 64;
   };
 
   // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
@@ -256,7 +230,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int k = 0; k < RW; k++) p[a][k] = ((a == 0 ? active : act1) && colok(k)) ? gp[(j0 + a) * SX + i0 + k] : real(0);
+    for (int k = 0; k < RW; k++) p[a][k] = (a == 0 ? active : act1) ? gp[(j0 + a) * SX + i0 + k] : real(0);
 
   // ---- action conditioning (rayleigh.py:162-171) / wall speeds (mixing.py:212-234) ----------
   real u_t = 0, u_b = 0, v_l = 0, v_r = 0;
@@ -359,7 +333,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         }
       }
     }
-    ex_put_east(xb, p[0][RW - 1], p[1][RW - 1]);
+    ex(xb, w, 1, 0)[lane] = p[0][RW - 1];
+    ex(xb, w, 1, 1)[lane] = p[1][RW - 1];
     __syncthreads();
     if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(0)
@@ -372,10 +347,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       // k-1 are written once column k is computed: by then every reader of the old column k-1 -- columns k-2, k-1, k of
       // this wave, all rows in the same instructions -- has its values in registers.  Only the strip's first and last
       // column are read by OTHER waves: they wait for the barrier.
-      real pWh0, pWh1;
-      ex_get(xb, wm, 1, pWh0, pWh1);
-      pWh0 = (w > 0) ? pWh0 : real(0);
-      pWh1 = (w > 0) ? pWh1 : real(0);
+      const real pWh0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0);
+      const real pWh1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
       xb ^= 1;
       // ring of columns i0-1 .. (loaded PF columns ahead of their use: the loads are global); column i0-1+q sits in slot q % NC
       constexpr int PF = 3, NC = 3 + PF;
@@ -450,10 +423,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) -> u*, v* (registers, then LDS) ---
     real us[2][RW], vs[2][RW];
     {
-      real pWh0, pWh1;
-      ex_get(xb, wm, 1, pWh0, pWh1);
-      pWh0 = (w > 0) ? pWh0 : real(0);
-      pWh1 = (w > 0) ? pWh1 : real(0);
+      const real pWh0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0);
+      const real pWh1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
       xb ^= 1;
 #pragma unroll
       for (int a = 0; a < 2; a++) {
@@ -503,7 +474,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int k = 0; k < RW; k++) {
-          if ((a == 1 && !act1) || !colok(k)) continue;
+          if (a == 1 && !act1) continue;
           Ul[(i0 + k) * SY + j0 + a] = us[a][k];
           Vl[(i0 + k) * SY + j0 + a] = vs[a][k];
         }
@@ -522,7 +493,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       for (int k = 0; k < RW; k++) {
         const int c = (i0 + k) * SY + j;
         const real div = (Ul[c + SY] - Ul[c]) * rdx + (Vl[c + 1] - Vl[c]) * rdy;
-        NB(a, k) = ((a == 0 ? active : act1) && colok(k)) ? -A.cb * div : real(0);
+        NB(a, k) = (a == 0 ? active : act1) ? -A.cb * div : real(0);
       }
     }
 
@@ -568,10 +539,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     }
 #define BCN_CELLS(SRC, DST)                                                                          \
       _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
-        /* single body: column RL - 1 of the last wave is the east wall (Neumann ghost = the cell itself) */ \
-        const real e0 = (ONE && k == RL - 1 && lastw) ? SRC[0][k] : SRC[0][k + 1];                   \
-        const real e1 = (ONE && k == RL - 1 && lastw) ? SRC[1][k] : SRC[1][k + 1];                   \
-        const real w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];                                           \
+        const real e0 = SRC[0][k + 1], e1 = SRC[1][k + 1], w0 = SRC[0][k - 1], w1 = SRC[1][k - 1];  \
         BCN_CELL(DST, SRC, k, e, w)                                                                  \
       }                                                                                              \
       __builtin_amdgcn_sched_barrier(0);   /* halo-dependent part stays behind the interior cells */ \
@@ -587,10 +555,15 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         const real e0 = hE0, e1 = hE1, w0 = SRC[0][RW - 2], w1 = SRC[1][RW - 2];                       \
         BCN_CELL(DST, SRC, RW - 1, e, w)                                                              \
       }                                                                                              \
-      ex_put(xb, DST[0][0], DST[1][0], DST[0][RW - 1], DST[1][RW - 1]);
+      ex(xb, w, 0, 0)[lane] = DST[0][0];                                                             \
+      ex(xb, w, 0, 1)[lane] = DST[1][0];                                                             \
+      ex(xb, w, 1, 0)[lane] = DST[0][RW - 1];                                                         \
+      ex(xb, w, 1, 1)[lane] = DST[1][RW - 1];
 #define BCN_HALO_READS                                                                               \
-      ex_get(xb, wm, 1, hW0r, hW1r);                                                                 \
-      ex_get(xb, wp, 0, hE0r, hE1r);                                                                 \
+      hW0r = ex(xb, wm, 1, 0)[lane];                                                                 \
+      hW1r = ex(xb, wm, 1, 1)[lane];                                                                 \
+      hE0r = ex(xb, wp, 0, 0)[lane];                                                                 \
+      hE1r = ex(xb, wp, 0, 1)[lane];                                                                 \
       xb ^= 1;
 #define BCN_FAST(SRC, DST) { BCN_CELLS(SRC, DST) __syncthreads(); itp++; BCN_HALO_READS }
 #define BCN_CHECK(SRC, DST, DST_IS_B)                                                                \
@@ -598,19 +571,12 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       BCN_CELLS(SRC, DST)                                                                            \
       real acc0 = 0, acc1 = 0;                                                                       \
       _Pragma("unroll") for (int k = 1; k < RW - 1; k++) {                                            \
-        real d0 = DST[0][k] - SRC[0][k], d1 = DST[1][k] - SRC[1][k];                                 \
-        /* single body, last wave: column RL - 1 is its east edge (below), the columns behind it are no cells (+ 0 keeps \
-           the sum bit for bit what the RL-column body added up) */                                  \
-        if (ONE && k >= RL - 1) { d0 = lastw ? real(0) : d0; d1 = lastw ? real(0) : d1; }            \
+        const real d0 = DST[0][k] - SRC[0][k], d1 = DST[1][k] - SRC[1][k];                           \
         acc0 += d0 * d0; acc1 += d1 * d1;                                                            \
       }                                                                                              \
       const real pI = wl0 * acc0 + wl1 * acc1;                                                       \
       real dW0 = DST[0][0] - SRC[0][0], dW1 = DST[1][0] - SRC[1][0];                                 \
       real dE0 = DST[0][RW - 1] - SRC[0][RW - 1], dE1 = DST[1][RW - 1] - SRC[1][RW - 1];                 \
-      if (ONE) {                                                                                     \
-        const real dL0 = DST[0][RL - 1] - SRC[0][RL - 1], dL1 = DST[1][RL - 1] - SRC[1][RL - 1];     \
-        dE0 = lastw ? dL0 : dE0; dE1 = lastw ? dL1 : dE1;                                            \
-      }                                                                                              \
       dW0 *= dW0; dW1 *= dW1; dE0 *= dE0; dE1 *= dE1;                                                \
       const real part = pI + (cW0 * dW0 + cW1 * dW1) + (cE0 * dE0 + cE1 * dE1);                      \
       const real tot63 = wave_sum_lane63<real>(part);                                                \
@@ -710,7 +676,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         const real pw = (k > 0) ? phA[a][k > 0 ? k - 1 : 0] : (a == 0 ? hW0 : hW1);
         const real ps = (a == 0) ? from_below(phA[1][k], phA[1][k]) : phA[0][k];
         p[a][k] += ph;
-        if ((a == 0 ? active : act1) && colok(k)) {
+        if (a == 0 ? active : act1) {
           const int c = i * SY + j;
           if (i >= 2) Ul[c] = Ul[c] - dt * (ph - pw) * rdx;
           if (j >= 2) Vl[c] = Vl[c] - dt * (ph - ps) * rdy;
@@ -772,7 +738,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int k = 0; k < RW; k++) if ((a == 0 || act1) && colok(k)) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
+          for (int k = 0; k < RW; k++) if (a == 0 || act1) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
       }
     }
     __syncthreads();
@@ -801,7 +767,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int k = 0; k < RW; k++) {
-        if ((a == 1 && !act1) || !colok(k)) continue;
+        if (a == 1 && !act1) continue;
         const int i = i0 + k, j = j0 + a, c = j * SX + i;
         const real dp = p[a][k] - gp[c];
         if (i == 1) gp[c - 1] += dp;
@@ -838,7 +804,7 @@ __device__ __forceinline__ void fast2_unit(const NS2DArgs<real>& A, const int b,
                                            const bool first_chunk, const bool last_chunk, char* smem) {
   using G = Fast2Geom<NX, NY, R, GF>;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (!G::ONE && G::RL != R && w == G::NW - 1)   // fields in the global scratch: a second instantiation for the narrower last strip
+  if (G::RL != R && w == G::NW - 1)
     fast2_body<real, NX, NY, R, G::RL, KIND, EQ, GF>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);
   else
     fast2_body<real, NX, NY, R, R, KIND, EQ, GF>(A, smem, w, b, it_begin, it_end, first_chunk, last_chunk);

@@ -101,8 +101,7 @@ def choose(nx, ny, f64, kind):
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx or (only and nw != only):
                 continue
             exch = 2 * nw * 4 * 64 + 160
-            padc = (r - rl) * (ny + 2) + 16 if rl != r else 0      # float32: one body for every strip (Fast2Geom::PADC)
-            lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2) + padc) * esz
+            lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
             if lds <= LDS_BYTES:
                 return {"rows": 2, "R": r, "gf": 1 if f64 else 0, "nw": nw}
     return _choose4(nx, ny, f64)

@@ -64,6 +64,8 @@ if not args.only or "shkadov" in args.only:
     B = 1024
     env = V.VecShkadov(B, dev, "f32", None, L0=699.2, n_jets=10)
     env.reset()
+    # from a developed film (shkadov/init.py: 4000 uncontrolled action steps under inlet noise), as bench.py's line
+    env.warmup(env.n_warmup_ref, torch.zeros((B, 10), dtype=torch.float32, device=dev))
     a = torch.as_tensor(rng.uniform(-1, 1, (K + W, B, 10)), dtype=torch.float32, device=dev)
     nz = torch.as_tensor(rng.uniform(-5e-4, 5e-4, (K + W, B, 50)), dtype=torch.float32, device=dev)
     wall, ms = timed(env, lambda k: env.step(a[k], nz[k]), K, W)
