@@ -23,6 +23,11 @@
 
 #include <type_traits>
 
+#ifndef BCN_PD2F
+#define BCN_PD2F 6    // steps per block of the float32 transport wave (two register sets: it runs PD .. 2 PD steps ahead); measured on the
+                      // same box, mixing bench workload, cycles per timestep outside the solve / per sweep: 4: 58.6 k / 1 262, 6: 57.2 k / 1 263,
+                      // 8: 56.6 k / 1 292 (the out-of-line function's register use changes the caller's allocation in the Jacobi loop)
+#endif
 #ifndef BCN_PDG2
 #define BCN_PDG2 8    // prefetch depth of the transport wave when the fields are in global memory
 #endif
@@ -114,7 +119,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int NX, int NY>
 __device__ __attribute__((noinline)) void transport_chain2_f32(float* Tl, const float* Ul, const float* Vl, float* dummy,
                                                                float c0x, float c1x, float c0y, float c1y) {
-  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2, PD = 4, NSTEP = NX + LH - 1;
+  constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2, PD = BCN_PD2F, NSTEP = NX + LH - 1;
   constexpr bool ODD = (NY & 1) != 0;
   const int lane = threadIdx.x & 63;
   // row 1: A += aS * S[i][0] (LDS accesses of one wave are in program order)
