@@ -12,6 +12,20 @@
  * (the reference env is not thread-safe either).  No call blocks on the GPU except
  * bcn_get_state/bcn_set_state with host pointers, and *_destroy.
  *
+ * Precision (measured on MI355X in round 4 against the float64 reference / its C restatement; the tests assert <= 10 x these
+ * figures, tests/test_gpu_parity.py: table F32, EPISODE_TOL, shkadov_tol):
+ *   BCN_F64: rayleigh / mixing fields and observations within 1e-9 with the reference's Jacobi sweep counts (measured 3e-15 ..
+ *            6e-15 over 400 timesteps); burgers, shkadov, sloshing fields bit-identical (rewards, being reductions, 1e-13).
+ *   BCN_F32, one action step: rayleigh 128x64 (200 timesteps, ~94 sweeps each) u, v 4e-7, T, p 1.3e-6, observations 1.2e-6,
+ *            reward (Nusselt number) 4e-6, every sweep count equal; mixing 100x100 (250 timesteps) u, v, C 2.5e-6, p 1.1e-5,
+ *            observations 1.2e-6, reward 2e-8; burgers observations 4e-6 on average (one step of a 200-step episode at 5e-5);
+ *            sloshing observations 8e-6; shkadov observations 1e-6 .. 2e-6, growing 1.4 x per action step (the film is chaotic).
+ *   BCN_F32, a whole 100-step episode against BCN_F64: rayleigh observations 2.3e-5 for the median replica, 2.5e-3 for the
+ *            worst one in its most sensitive transient (the flow amplifies rounding-level differences ~3000 x there: two
+ *            float64 kernels drift apart with the same profile), 7e-5 at the end of the episode; mixing 1.8e-4 (median) /
+ *            8.5e-4 (worst probe), rewards 1e-5; shkadov: trajectories decorrelate after ~40 steps, episode-return statistics
+ *            over 64 replicas agree to 3e-4 sigma.
+ *
  * Return value: 0 = BCN_OK, otherwise a BCN_ERR_* code; bcn_last_error() gives text.
  * Solver failures never exit the process (the reference does: rayleigh.py:221-224);
  * they are reported per replica in status_dev (BCN_ST_* bits).

@@ -2026,6 +2026,25 @@ def test_c_abi_error_behaviour():
     lib = _lib.load()
     assert lib.bcn_batch(None) == 0 and lib.bcn_destroy(None) == 0            # NULL handle: inert, like free(NULL)
     assert lib.bcn_get_state(None, None, 0, None) == 1 and b"null" in lib.bcn_last_error()   # BCN_ERR_ARG
+    # the sized counters call writes exactly words_per_replica words per replica (a caller built against an older header
+    # that allocated 2 words per replica is not overrun), the unsized one BCN_COUNTER_WORDS; the API version is exported
+    import ctypes as C
+    assert lib.bcn_api_version() == _lib.API_VERSION
+    env = V.VecRayleigh(3, DEV, "f32", E.packaged_init("rayleigh"))
+    env.set_ndt_act(4)
+    env.reset()
+    env.step(np.zeros((3, 10)))
+    full = env.get_counters()
+    assert full.shape == (3, _lib.COUNTER_WORDS) and int(full[:, 1].min()) > 0
+    for words in (2, 6):
+        buf = (C.c_uint64 * (3 * words + 1))(*([0xdeadbeef] * (3 * words + 1)))
+        assert lib.bcn_get_counters_n(env.h, buf, words, env._stream()) == 0
+        got = np.frombuffer(buf, dtype=np.uint64)
+        assert int(got[-1]) == 0xdeadbeef                                  # nothing behind the requested words
+        got = got[:-1].reshape(3, words)
+        assert np.array_equal(got[:, :min(words, 4)], full[:, :min(words, 4)]) and not got[:, 4:].any()
+    assert lib.bcn_get_counters_n(env.h, buf, 0, env._stream()) == 1
+    env.close()
 
 
 def test_plain_c_consumer_of_the_c_abi(tmp_path):

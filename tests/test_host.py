@@ -28,6 +28,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name)
     assert b"gfx950" in L.bcn_version()
+    hdr_ver = int(re.search(r"#define BCN_API_VERSION (\d+)", hdr).group(1))
+    assert L.bcn_api_version() == hdr_ver == _lib.API_VERSION          # header, library and binding agree
     raw = ctypes.CDLL(_lib.lib_path())
     for name in declared:
         getattr(raw, name)
