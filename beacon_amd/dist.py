@@ -7,12 +7,14 @@ rank 0 scatters actions[B_global, n_act] (and replica masks) and gathers the pac
 
 One process per GPU; the message is ~100-800 KB per rank per step, i.e. latency-bound.
 
-The gather does not have to sit between two steps: with `overlap=True` the local env alternates between two
-packed output buffers (VecEnv.double_buffer: step k writes buffer k % 2) and step_async() issues the gather
+The gather does not have to sit between two steps: with `overlap=True` the local env rotates through THREE
+packed output buffers (VecEnv.double_buffer: step k writes buffer k % 3) and step_async() issues the gather
 of step k on a SIDE stream behind an event, so the kernel of step k + 1 is enqueued directly behind the kernel
-of step k; the gather of step k is waited for only by whoever reads its result and by step k + 2, which
-overwrites the buffer it reads.  (A trainer whose actions of step k + 1 depend on the observations of step k
+of step k; the gather of step k is waited for only by whoever reads its result and by step k + 3, which
+overwrites the buffer it reads.  (Three, not two: the step kernels are persistent and occupy every CU, so the
+gather's kernel gets a CU only while step k + 1 drains -- with two buffers step k + 2 would have to wait for it.)  (A trainer whose actions of step k + 1 depend on the observations of step k
 calls step(), which is step_async().wait(): nothing can overlap then, by the data dependence itself.)"""
+import os
 import torch
 import torch.distributed as dist
 
@@ -100,11 +102,13 @@ class PendingStep(object):
     packed outputs on the env's side stream.  wait() makes the CALLER'S CURRENT STREAM wait for that gather (no host
     synchronisation on device tensors; with gloo / CPU tensors it blocks the host until the collective is done) and
     returns (obs, rwd, done, trunc, None) on rank 0, (None, ...) elsewhere.  The tensors are views of a receive buffer
-    that the gather of the step after next overwrites."""
+    that the gather NBUF steps later overwrites; that gather waits for everything enqueued until then on the stream
+    wait() was called on, so a consumer on its own stream (a trainer's copy stream) needs no further synchronisation."""
 
     def __init__(self, senv, full, work, done_event):
         self.senv, self.full, self.work, self.done_event = senv, full, work, done_event
         self.result = None
+        self.consumer = None          # the stream wait() was called on
 
     def _finish(self):
         """Host side of the collective (gloo): block until it is done.  Device side (nccl): nothing to do here."""
@@ -117,7 +121,8 @@ class PendingStep(object):
             return self.result
         self._finish()
         if self.done_event is not None:
-            torch.cuda.current_stream(self.senv.env.device).wait_event(self.done_event)
+            self.consumer = torch.cuda.current_stream(self.senv.env.device)
+            self.consumer.wait_event(self.done_event)
         e = self.senv.env
         if self.full is None:
             self.result = (None, None, None, None, None)
@@ -142,6 +147,8 @@ class ShardedVecEnv(object):
     stream; `seed` defaults to the seed the env itself was constructed with (VecBurgers(seed=...)), and an
     unsharded env (world size 1) keeps its generator untouched."""
 
+    NBUF = int(os.environ.get("BEACON_NBUF", "3"))      # output buffers of the overlapped path (>= 2)
+
     def __init__(self, local_env, group=None, seed=None, always_collective=False, overlap=False):
         self.env = local_env
         self.sh = ReplicaSharder(local_env.batch, group, always_collective)
@@ -149,10 +156,11 @@ class ShardedVecEnv(object):
         self.lo, self.hi = shard_bounds(self.global_batch, self.sh.world, self.sh.rank)
         self.status = None
         self.overlap = bool(overlap) and self.sh.collective
-        self._pending = [None, None]          # gather in flight per output buffer
+        self._pending = [None] * self.NBUF    # gather in flight per output buffer
+        self._consumers = [None] * self.NBUF  # stream that took delivery of the previous gather into that receive area
         self._side = None
         if self.overlap:
-            local_env.double_buffer(True)
+            local_env.double_buffer(True, self.NBUF)
             if torch.device(local_env.device).type == "cuda":
                 self._side = torch.cuda.Stream(device=local_env.device)
         if getattr(local_env, "gen", None) is not None and (self.sh.world > 1 or seed is not None):
@@ -184,10 +192,16 @@ class ShardedVecEnv(object):
     def _drain(self):
         """Everything in flight is finished from the caller's stream's point of view (before a blocking collective on
         the main stream touches the buffers)."""
+        main = torch.cuda.current_stream(self.env.device) if self._side is not None else None
         for k, p in enumerate(self._pending):
+            cons = self._consumers[k]
             if p is not None:
                 p.wait()
+                cons = p.consumer if p.consumer is not None else cons
                 self._pending[k] = None
+            if cons is not None and cons != main:     # delivered on another stream: its reads of the receive area first
+                main.wait_stream(cons)
+            self._consumers[k] = None
 
     def _gather(self):
         e = self.env
@@ -210,6 +224,10 @@ class ShardedVecEnv(object):
             done = torch.cuda.Event()
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ready)
+                cons = self._consumers[k]              # whoever read this receive area NBUF steps ago, on its own stream
+                if cons is not None and cons != main:
+                    self._side.wait_stream(cons)
+                self._consumers[k] = None
                 full, work = self.sh.gather(name, e.out_buf, async_op=True)
                 if work is not None:
                     work.wait()                        # side stream waits for the backend's stream; the host does not
@@ -258,13 +276,14 @@ class ShardedVecEnv(object):
                 obs, rwd, self.status, done, trunc = g
                 p.result = (obs, rwd, done, trunc, None)
             return p
-        # the step about to be enqueued writes the OTHER buffer: the gather that still reads it (two steps back) first
-        nxt = 1 - e._cur
+        # the step about to be enqueued writes the NEXT buffer of the ring: the gather that still reads it (NBUF steps back) first
+        nxt = (e._cur + 1) % self.NBUF
         old = self._pending[nxt]
         if old is not None:
             old._finish()
             if old.done_event is not None:
                 torch.cuda.current_stream(e.device).wait_event(old.done_event)
+            self._consumers[nxt] = old.consumer
             self._pending[nxt] = None
         e.step(local, noise, mask=m)
         return self._gather_async()

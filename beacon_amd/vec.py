@@ -81,7 +81,7 @@ class VecEnv(object):
         reset() / step() wrote."""
         B, esz = self.batch, torch.empty((), dtype=self.tdtype).element_size()
         self.out_layout = out_layout(B, self.obs_dim, esz)
-        self.out_bufs, self._views, self._rotate = [], [], False
+        self.out_bufs, self._views, self._rotate = [], [], 0
         self._add_out_buf()
         self._bind_outputs(0)
 
@@ -95,27 +95,27 @@ class VecEnv(object):
         self.out_buf = self.out_bufs[k]
         self.obs, self.rwd, self.status, self.done, self.trunc = self._views[k]
 
-    def double_buffer(self, on=True):
-        """Alternate between TWO packed output buffers: step k writes buffer k % 2, so that a consumer of step k's
+    def double_buffer(self, on=True, nbuf=2):
+        """Rotate through `nbuf` packed output buffers: step k writes buffer k % nbuf, so that a consumer of step k's
         outputs on another stream -- the sharded batch's gather to rank 0 (beacon_amd/dist.py), a device-to-host copy --
-        may still be reading them while step k + 1 runs.  After every step() the attributes obs / rwd / done / trunc /
-        status / out_buf are re-bound to the buffer that step wrote (so hold on to the tensors a step RETURNS, not to
-        the attributes, and expect them to be overwritten by the step after next).  reset() writes the current buffer.
+        may still be reading them while the next nbuf - 1 steps run.  After every step() the attributes obs / rwd / done /
+        trunc / status / out_buf are re-bound to the buffer that step wrote (so hold on to the tensors a step RETURNS, not
+        to the attributes, and expect them to be overwritten nbuf steps later).  reset() writes the current buffer.
         A step with a replica mask first copies the previous buffer (the rows of skipped replicas keep their values).
         Not for captured graphs (StepGraph records fixed addresses)."""
-        if on and len(self.out_bufs) == 1:
+        while on and len(self.out_bufs) < int(nbuf):
             self._add_out_buf()
-        self._rotate = bool(on)
+        self._rotate = int(nbuf) if on else 0
         if not on:
             self._bind_outputs(self._cur)
         return self
 
     def _next_outputs(self, carry):
-        """Called by step() before the launch: with double buffering, switch to the other buffer."""
+        """Called by step() before the launch: with rotating outputs, switch to the next buffer."""
         if not self._rotate:
             return
         prev = self.out_buf
-        self._bind_outputs(1 - self._cur)
+        self._bind_outputs((self._cur + 1) % self._rotate)
         if carry:
             self.out_buf.copy_(prev)
 

@@ -524,6 +524,16 @@ def main():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_ev else []
         sweeps_all = []
         pend = None
+        # rank 0 takes delivery on its own stream, as a trainer's copy stream would: the step stream never waits for a gather
+        # younger than three steps (ShardedVecEnv.NBUF output buffers)
+        consumer = torch.cuda.Stream(device=dev) if (use_ev and collective and senv.overlap) else None
+
+        def deliver(p_):
+            if consumer is None:
+                p_.wait()
+            else:
+                with torch.cuda.stream(consumer):
+                    p_.wait()
         t0 = time.perf_counter()
         for k in range(K):
             if use_ev:
@@ -539,10 +549,10 @@ def main():
             if collective and not senv.overlap:
                 senv._gather()                          # --no-overlap: blocking collective between two steps
             if pend is not None:
-                pend.wait()                             # rank 0 takes delivery of step k - 1 while step k runs
+                deliver(pend)                           # rank 0 takes delivery of step k - 1 while step k runs
             pend = p
         if pend is not None:
-            pend.wait()
+            deliver(pend)
         sync()
         elapsed = time.perf_counter() - t0
         env.check_status()

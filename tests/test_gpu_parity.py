@@ -2293,20 +2293,29 @@ for name in ("rayleigh", "burgers"):
 # the gather on a side stream beside the next step (double-buffered outputs): step_async, results taken one step late
 def make():
     e = V.VecRayleigh(B, dev, "f32", packaged_init("rayleigh")); e.set_ndt_act(10); return e
-acts = torch.as_tensor(rng.uniform(-1, 1, (6, B, 10)), dtype=torch.float32, device=dev)
-senv = ShardedVecEnv(make(), always_collective=True, overlap=True)
-assert senv.overlap and senv._side is not None and len(senv.env.out_bufs) == 2
-ref = make(); ref.reset(); senv.reset()
-pend, outs = [], []
-for k in range(6):
-    pend.append(senv.step_async(acts[k]))
-    if len(pend) == 2:
-        outs.append([x.clone() for x in pend.pop(0).wait()[:4]])
-outs.append([x.clone() for x in pend.pop(0).wait()[:4]])
-for k in range(6):
-    o, r, d, t, _ = ref.step(acts[k])
-    assert torch.equal(outs[k][0], o) and torch.equal(outs[k][1], r) and torch.equal(outs[k][2], d), k
-ref.close(); senv.close()
+acts = torch.as_tensor(rng.uniform(-1, 1, (8, B, 10)), dtype=torch.float32, device=dev)
+for late, own_stream in ((1, False), (2, True)):
+    # results taken `late` steps late (2 = as late as the ring of three output buffers allows), on the step stream or on a
+    # consumer stream of their own (the next gather into that receive area must wait for the consumer's reads)
+    senv = ShardedVecEnv(make(), always_collective=True, overlap=True)
+    assert senv.overlap and senv._side is not None and len(senv.env.out_bufs) == 3
+    ref = make(); ref.reset(); senv.reset()
+    cons = torch.cuda.Stream(device=dev) if own_stream else torch.cuda.current_stream(dev)
+    pend, outs = [], []
+    def take():
+        with torch.cuda.stream(cons):
+            outs.append([x.clone() for x in pend.pop(0).wait()[:4]])
+    for k in range(8):
+        pend.append(senv.step_async(acts[k]))
+        if len(pend) == late + 1:
+            take()
+    while pend:
+        take()
+    torch.cuda.synchronize()
+    for k in range(8):
+        o, r, d, t, _ = ref.step(acts[k])
+        assert torch.equal(outs[k][0], o) and torch.equal(outs[k][1], r) and torch.equal(outs[k][2], d), (late, k)
+    ref.close(); senv.close()
 # masks, single-env resets and auto-reset through the sharded env == the plain env, bit for bit
 stp0 = np.array([97, 98, 99, 96, 99, 98], dtype=np.int32)
 for overlap in (False, True):

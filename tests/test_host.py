@@ -250,7 +250,7 @@ assert sum(int(x[2].sum()) for x in ref_log if len(x) == 4) >= 20      # episode
 for overlap in (False, True):
     loc = CpuVecEnv(B, n_act=NA)
     senv = ShardedVecEnv(loc, overlap=overlap)
-    assert senv.overlap == overlap and (len(loc.out_bufs) == 2) == overlap
+    assert senv.overlap == overlap and (len(loc.out_bufs) == senv.NBUF) == overlap
     got = script(senv, True)
     if rank == 0:
         assert len(got) == len(ref_log)
