@@ -165,7 +165,13 @@ struct NS2DEnv : bcn_env_s {
   }
   int launch(hipStream_t s) {
     a.launched = &launched;
-    if (variant == 1 && plugin) return plugin(&a, batch, s);
+    if (variant == 1 && plugin) {
+      // BCN_ERR_UNSUPPORTED: the batch does not fit the plugin's addressing (ns2d_fast4_impl.h: 32-bit offsets from a
+      // replica's u): the generic kernel takes the step
+      const int rc = plugin(&a, batch, s);
+      if (rc != BCN_ERR_UNSUPPORTED) return rc;
+      return ns2d_launch_generic<real>(a, batch, s);
+    }
     if (variant == 1) return ns2d_launch_fast<real>(a, batch, s);
     return ns2d_launch_generic<real>(a, batch, s);
   }

@@ -75,6 +75,12 @@ struct Fast4Geom {
 template <int NX, int NW, int U, class LD, class ST>
 __device__ __forceinline__ void f4_cells(int w, int tx, int j_lo, int j_hi, LD&& ld, ST&& st) {
   constexpr int CPL = (NX + BCN_WAVE - 1) / BCN_WAVE;
+#ifndef BCN_F4_NO_LAUNDER
+  // the lane's indices are recomputed in every phase (a few VALU instructions): left to itself hipcc hoists them out of
+  // the timestep loop, keeps them live across the Poisson solve -- where every register is taken -- and reloads them from
+  // scratch at each use
+  asm volatile("" : "+v"(tx));
+#endif
   for (int jb = j_lo + w; jb <= j_hi; jb += NW * U) {
     decltype(ld(0, 0)) vals[U][CPL];
 #pragma unroll
@@ -95,10 +101,125 @@ __device__ __forceinline__ void f4_cells(int w, int tx, int j_lo, int j_hi, LD&&
   }
 }
 
+// A replica's field in HBM behind ONE buffer descriptor for its six fields (four SGPRs: base = the replica's u, which
+// the host lays out as [6][B][ncell], so field f starts f * B * ncell elements further on: `so`, an SGPR byte offset) and
+// ONE 32-bit byte offset per lane: `buffer_load_dword v, v_off, s[rsrc], s_so offen offset:imm`.  As plain `real*` a lane
+// keeps a 64-bit address per field; the 128-register budget spilled them, and every access then reloaded its address from
+// scratch behind an s_waitcnt vmcnt(0), i.e. the loads of a batch went out one by one (round 4).
+template <typename real> struct F4Field {
+  __amdgpu_buffer_rsrc_t rs;
+  int so;
+  struct Ref {
+    const F4Field& f;
+    int i;
+    __device__ __forceinline__ operator real() const { return f.ld(i); }
+    __device__ __forceinline__ void operator=(real x) const { f.st(i, x); }
+    __device__ __forceinline__ void operator=(const Ref& o) const { f.st(i, real(o)); }
+  };
+  __device__ __forceinline__ real ld(int i) const {
+    if constexpr (sizeof(real) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, i * 4, so, 0));
+    else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, i * 8, so, 0));
+  }
+  __device__ __forceinline__ void st(int i, real x) const {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(real) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), rs, i * 4, so, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rs, i * 8, so, 0);
+  }
+  __device__ __forceinline__ Ref operator[](int i) const { return Ref{*this, i}; }
+};
+// the layout the descriptor relies on, checked on the host before a launch: the five other fields behind u, everything a
+// replica touches within 2 GB of its u (the byte offsets are 32-bit)
+template <typename real> inline bool f4_fields_ok(const NS2DArgs<real>& a, size_t ncell) {
+  const real* f[6] = {a.u, a.v, a.p, a.S, a.us, a.vs};
+  for (int k = 1; k < 6; k++)
+    if (f[k] < a.u || ((size_t)(f[k] - a.u) + ncell) * sizeof(real) >= 0x7fffffffull) return false;
+  return true;
+}
 template <typename real> struct F4Pred { real u[6], v[6], p[3], s; };
 template <typename real> struct F4Rhs { real u0, u1, v0, v1; };
 template <typename real> struct F4Corr { real p, us, vs, gx, gy; };
 template <typename real> struct F4Tr { real uW, uE, vS, vN, Tc, TE, TN, TW; };
+
+// One Jacobi sweep of a wave's column strip in registers, WITHOUT a register copy: the columns shift by one slot per sweep.
+// An in-place sweep keeps a column's new values in temporaries until its east neighbour has used the old ones and moves
+// them home afterwards (70 v_mov of 240 instructions at 7 x 4 cells per lane).  Instead, with R + 1 slots for R columns:
+//   DIRB = false (state X -> Y): east -> west, column k from slots k - 1, k, k + 1 into slot k + 1 -- the old column k + 1
+//                                there is dead by then (both its neighbours and the column itself are done);
+//   DIRB = true  (state Y -> X): west -> east, column k from slots k, k + 1, k + 2 into slot k -- which holds the old
+//                                column k - 1, dead for the same reason.
+// Same arithmetic per cell as ever (rayleigh.py:428-444), in another order of the columns only.
+//
+// Edge exchange of a sweep without residual: ONE barrier, in the MIDDLE of the sweep.  The first column a sweep computes is an edge column: it goes
+// to the neighbour strip's halo slot at once (the "early" product), the last column when the sweep ends (the "late" one).
+// The next sweep runs the other way round, so it needs FIRST the halo its neighbour produced early and LAST the one
+// produced late: the early halo was written before the previous sweep's barrier (readable with no wait at all), the late
+// one before the neighbour reaches this sweep's barrier -- it is read right behind that barrier and used half a sweep
+// later.  No LDS latency and no barrier skew is exposed between two sweeps.  Halo slots: hal[parity][wave][west|east]; a
+// sweep reads parity `par` and writes `par ^ 1`, and parity == state (0: X), so every slot has one writer phase and one
+// reader phase per double sweep, separated by the barriers.
+//   first_rd / last_rd: the halo needed by the first / last column of this direction; first_wr / last_wr: where the first /
+//   last column goes.  RC: columns of this strip (R, or RL in the last wave).  RC == 1 (last wave only, whose east "halo"
+//   is its own slot): the barrier sits where the one foreign dependence needs it.
+// EV: accumulates the squared increments (acc per row, accW / accE of the strip's first / last column) for the stop test.
+template <typename real, int R, int RPL, int RC, int KIND, bool EQ, int RT, bool DIRB, bool EV>
+__device__ __forceinline__ void f4_sweep(real (&Pv)[R + 1][RPL], const real (&Bv)[R][RPL], const real (&cxr)[RPL],
+                                         const real (&cyr)[RPL], const real tmask, const real* first_rd, const real* last_rd,
+                                         real* first_wr, real* last_wr, real (&acc)[RPL], real& accW, real& accE) {
+  static_assert(RC >= 1 && RC <= R, "columns of the strip");
+  // position (in processing order) in front of which the barrier sits; -1: none -- an evaluated sweep ends with a barrier
+  // of its own (the workgroup reduction), and the caller puts one between a run of plain sweeps and an evaluated one, so
+  // that an evaluated sweep finds both halos complete when it starts
+  constexpr int PB = EV ? -1 : (RC >= 2) ? (RC / 2 > 1 ? RC / 2 : 1) : (DIRB ? 1 : 0);
+  real hf[RPL], hl[RPL];
+  if (PB == 0) __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RPL; r++) hf[r] = first_rd[r];
+  if (PB <= 0 || PB >= RC) {
+#pragma unroll
+    for (int r = 0; r < RPL; r++) hl[r] = last_rd[r];
+  }
+#pragma unroll
+  for (int pos = 0; pos < RC; pos++) {
+    const int k = DIRB ? pos : RC - 1 - pos;
+    if (pos == PB && PB > 0) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RPL; r++) hl[r] = last_rd[r];
+    }
+    real cv[RPL], wv[RPL], ev[RPL], out[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+      cv[r] = DIRB ? Pv[k + 1][r] : Pv[k][r];
+      if (k == 0) wv[r] = DIRB ? hf[r] : hl[r];
+      else wv[r] = DIRB ? Pv[k][r] : Pv[k > 0 ? k - 1 : 0][r];
+      if (k == RC - 1) ev[r] = DIRB ? hl[r] : hf[r];
+      else ev[r] = DIRB ? Pv[k + 2 <= R ? k + 2 : R][r] : Pv[k + 1][r];
+    }
+    const real sdn = from_below<real>(cv[0], cv[RPL - 1]);
+    const real nup = dpp<0x130, 0xf, 0xf, true>(real(0), cv[0]);
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+      const real s = (r == 0) ? sdn : cv[r > 0 ? r - 1 : 0];
+      real n = (r == RPL - 1) ? nup : cv[r + 1 < RPL ? r + 1 : r];
+      if (KIND == 0 && r == RT) n = tmask * cv[r] + n;
+      if constexpr (EQ) out[r] = cxr[r] * ((ev[r] + wv[r]) + (n + s)) + Bv[k][r];
+      else out[r] = cyr[r] * (n + s) + (cxr[r] * (ev[r] + wv[r]) + Bv[k][r]);
+      if (EV) {
+        const real d = out[r] - cv[r];
+        acc[r] += d * d;
+        if (k == 0) accW += d * d;
+        if (k == RC - 1) accE += d * d;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+      if (DIRB) Pv[k][r] = out[r]; else Pv[k + 1][r] = out[r];
+      if (pos == 0) first_wr[r] = out[r];
+      if (pos == RC - 1) last_wr[r] = out[r];
+    }
+  }
+  if (PB >= RC) __syncthreads();
+}
 
 // timesteps [it_begin, it_end) of replica b: the whole action step (plain launch) or one chunk of it (ticket scheduler,
 // ns2d_sched.h: the replica's state lives in HBM between timesteps anyway, so a chunk needs no load / store of its own)
@@ -108,8 +229,12 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
   using G = Fast4Geom<NX, NY, R, RPL>;
   constexpr int NW = G::NW, NT = G::NT, SX = G::SX, P = G::P, RL = G::RL, NL = G::NL, RT = G::RT, CPL = G::CPL, HROWS = G::HROWS;
   constexpr int BR = G::br(sizeof(real)), NBLK = G::nblk(sizeof(real));
+  static_assert(R >= 2, "f4_sweep: a strip other than the last one has at least two columns");
 #ifndef BCN_F4_U
 #define BCN_F4_U 2
+#endif
+#ifndef BCN_F4_STATIC_DIR   // shape of the Jacobi loop (see there)
+#define BCN_F4_STATIC_DIR(real) (sizeof(real) == 8)
 #endif
   constexpr int U = (CPL >= BCN_F4_U) ? 1 : BCN_F4_U / CPL;   // rows of a lane in flight in the HBM/L2 phases
   const int tid = threadIdx.x;
@@ -124,12 +249,22 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
   struct alignas(2 * sizeof(real)) F4YZ { real y, z; };   // aW, aS of a cell side by side: one LDS access in the walk
   F4YZ* TYZ = reinterpret_cast<F4YZ*>(TX + ((BR * P + 1) & ~1));
 
+#ifdef BCN_F4_PTR64   // experiment: plain 64-bit addresses per lane and field
   real* __restrict__ u = A.u + off;
   real* __restrict__ v = A.v + off;
   real* __restrict__ p = A.p + off;
   real* __restrict__ S = A.S + off;
   real* __restrict__ us = A.us + off;
   real* __restrict__ vs = A.vs + off;
+#else
+  // (the descriptor must be provably wave-uniform, or hipcc wraps every access in a waterfall loop: b comes out of LDS in
+  //  the ticket scheduler)
+  const int bu = __builtin_amdgcn_readfirstlane(b);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(A.u + (size_t)bu * G::NCELL, 0, 0x7fffffff, 0x00020000);
+  const F4Field<real> u{rs, 0}, v{rs, (int)((A.v - A.u) * (long)sizeof(real))}, p{rs, (int)((A.p - A.u) * (long)sizeof(real))},
+      S{rs, (int)((A.S - A.u) * (long)sizeof(real))}, us{rs, (int)((A.us - A.u) * (long)sizeof(real))},
+      vs{rs, (int)((A.vs - A.u) * (long)sizeof(real))};
+#endif
 
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_jac = 0, n_eval = 0, n_late = 0, n_redo = 0;
@@ -282,7 +417,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
 
     // ---- Jacobi sweeps in registers (rayleigh.py:419-454 / mixing.py:428-463) ----
     const unsigned long long tj0 = __builtin_amdgcn_s_memtime();
-    real Pv[R][RPL], Bv[R][RPL];
+    real Pv[R + 1][RPL], Bv[R][RPL];   // R columns in R + 1 slots: f4_sweep shifts them by one per sweep
 #pragma unroll
     for (int k = 0; k < R; k++)
 #pragma unroll
@@ -292,83 +427,54 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
       }
     int itp = 0, par = 0;
     real err = 0, eU = 0;
-    // One sweep, in place (a column is overwritten once its west neighbour no longer needs the old values).  EV: with the
-    // residual of the reference's stop test (weighted: ghosts copy their interior neighbour, one more count per Neumann side)
-    // and the plain sum of squares the evaluation plan works with; their workgroup reduction shares the barrier of the
-    // edge exchange.
-    // (a macro, not a lambda: with the register arrays captured by reference hipcc turned `lastw ? Pv[RL - 1][r] : Pv[R - 1][r]`
-    //  into a run-time index and moved the array to scratch memory)
-#ifdef BCN_F4_NOBAR   // timing experiments only (wrong results)
-#define BCN_F4_BAR(EV) if (EV) __syncthreads();
-#else
-#define BCN_F4_BAR(EV) __syncthreads();
-#endif
-#define BCN_F4_SWEEP(EV) {                                                                                                         \
-      real west[RPL], east[RPL], acc[RPL], accW = 0, accE = 0;                                                                     \
+    // The sweeps (f4_sweep above; state == parity of the halo buffers: 0 = X).  Evaluated: with the residual of the reference's stop test
+    // (weighted: ghosts copy their interior neighbour, one more count per Neumann side) and the plain sum of squares the
+    // evaluation plan works with, reduced over the workgroup behind a barrier of its own at the end of the sweep.
+    // (a macro around the calls: the wave-uniform branch on `lastw` picks the instantiation, so that no register array is
+    //  ever indexed by a run-time value)
+#define BCN_F4_CALL(RC_, DIRB_, EV_)                                                                                               \
+      f4_sweep<real, R, RPL, RC_, KIND, EQ, RT, DIRB_, EV_>(Pv, Bv, cxr, cyr, tmask,                                               \
+          (DIRB_ ? hw_rd0 + HPAR : he_rd0), (DIRB_ ? he_rd0 + HPAR : hw_rd0),                                                      \
+          (DIRB_ ? hw_wr0 : he_wr0 + HPAR), (DIRB_ ? he_wr0 : hw_wr0 + HPAR), acc, accW, accE);
+    // an evaluated sweep of direction DIRB_ (state X -> Y: false)
+#define BCN_F4_EVAL(DIRB_) {                                                                                                       \
+      real acc[RPL], accW = 0, accE = 0;                                                                                           \
       _Pragma("unroll")                                                                                                            \
-      for (int r = 0; r < RPL; r++) {                                                                                              \
-        west[r] = hw_rd0[par * HPAR + r];                                                                                          \
-        east[r] = he_rd0[par * HPAR + r];                                                                                          \
-        acc[r] = 0;                                                                                                                \
-      }                                                                                                                            \
+      for (int r = 0; r < RPL; r++) acc[r] = 0;                                                                                    \
+      if (RL < R && lastw) BCN_F4_CALL(RL, DIRB_, true) else BCN_F4_CALL(R, DIRB_, true)                                           \
+      constexpr int np = DIRB_ ? 0 : 1;                                                                                            \
+      real plain = 0;                                                                                                              \
       _Pragma("unroll")                                                                                                            \
-      for (int k = 0; k < R; k++) {                                                                                                \
-        if (k < RL || !lastw) {                                                                                                    \
-          real cur[RPL];                                                                                                           \
-      _Pragma("unroll")                                                                                                            \
-          for (int r = 0; r < RPL; r++) cur[r] = Pv[k][r];                                                                         \
-          const real sdn = from_below<real>(cur[0], cur[RPL - 1]);                                                                 \
-          real nup = dpp<0x130, 0xf, 0xf, true>(real(0), cur[0]);                                                                  \
-      _Pragma("unroll")                                                                                                            \
-          for (int r = 0; r < RPL; r++) {                                                                                          \
-            const real s = (r == 0) ? sdn : cur[r - 1];                                                                            \
-            real n = (r == RPL - 1) ? nup : cur[r + 1 < RPL ? r + 1 : r];                                                          \
-            if (KIND == 0 && r == RT) n = tmask * cur[r] + n;                                                                      \
-            real e;                                                                                                                \
-            if (k == R - 1) e = east[r];                                                                                           \
-            else if (k == RL - 1) e = lastw ? east[r] : Pv[k + 1 < R ? k + 1 : k][r];                                              \
-            else e = Pv[k + 1 < R ? k + 1 : k][r];                                                                                 \
-            const real wv = west[r];                                                                                               \
-            real ph;                                                                                                               \
-            if constexpr (EQ) ph = cxr[r] * ((e + wv) + (n + s)) + Bv[k][r];                                                       \
-            else ph = cyr[r] * (n + s) + (cxr[r] * (e + wv) + Bv[k][r]);                                                               \
-            if (EV) {                                                                                                              \
-              const real d = ph - cur[r];                                                                                          \
-              acc[r] += d * d;                                                                                                     \
-              if (k == 0) accW += d * d;                                                                                           \
-              if (k == RL - 1) accE += d * d;                                                                                      \
-            }                                                                                                                      \
-            Pv[k][r] = ph;                                                                                                         \
-            west[r] = cur[r];                                                                                                      \
-          }                                                                                                                        \
-        }                                                                                                                          \
-      }                                                                                                                            \
-      const int np = par ^ 1;                                                                                                      \
-      _Pragma("unroll")                                                                                                            \
-      for (int r = 0; r < RPL; r++) {                                                                                              \
-        hw_wr0[np * HPAR + r] = Pv[0][r];                                                                                          \
-        he_wr0[np * HPAR + r] = lastw ? Pv[RL - 1][r] : Pv[R - 1][r];                                                              \
-      }                                                                                                                            \
-      if (EV) {                                                                                                                    \
-        real plain = 0;                                                                                                            \
-      _Pragma("unroll")                                                                                                            \
-        for (int r = 0; r < RPL; r++) plain += acc[r];                                                                             \
-        real loc = plain + bmask * acc[0];                                                                                         \
-        if constexpr (KIND == 0) loc += tmask * acc[RT];                                                                           \
-        if (w == 0) loc += accW;                                                                                                   \
-        if (lastw) loc += accE;                                                                                                    \
-        loc = wave_sum_lane63<real>(loc);                                                                                          \
-        plain = wave_sum_lane63<real>(plain);                                                                                      \
-        if (tx == BCN_WAVE - 1) { red[np * 32 + w] = loc; red[np * 32 + 16 + w] = plain; }                                         \
-      }                                                                                                                            \
-      BCN_F4_BAR(EV)                                                                                                                \
+      for (int r = 0; r < RPL; r++) plain += acc[r];                                                                               \
+      real loc = plain + bmask * acc[0];                                                                                           \
+      if constexpr (KIND == 0) loc += tmask * acc[RT];                                                                             \
+      if (w == 0) loc += accW;                                                                                                     \
+      if (lastw) loc += accE;                                                                                                      \
+      loc = wave_sum_lane63<real>(loc);                                                                                            \
+      plain = wave_sum_lane63<real>(plain);                                                                                        \
+      if (tx == BCN_WAVE - 1) { red[np * 32 + w] = loc; red[np * 32 + 16 + w] = plain; }                                           \
+      __syncthreads();                                                                                                             \
       par = np;                                                                                                                    \
       itp++;                                                                                                                       \
-      if (EV) {                                                                                                                    \
-        const real eW_ = red[np * 32 + (tx & 15)], eU_ = red[np * 32 + 16 + (tx & 15)];                                            \
-        err = read_lane(row16_sum<real>(eW_), 15);                                                                                 \
-        eU = read_lane(row16_sum<real>(eU_), 15);                                                                                  \
+      const real eW_ = red[np * 32 + (tx & 15)], eU_ = red[np * 32 + 16 + (tx & 15)];                                              \
+      err = read_lane(row16_sum<real>(eW_), 15);                                                                                   \
+      eU = read_lane(row16_sum<real>(eU_), 15);                                                                                    \
+    }
+    // sweeps without residual, two at a time from state DIRB_ (false: X) while n >= 2: straight-line code, no merge of the
+    // two directions' register assignments inside the loop; and a single one
+#define BCN_F4_PAIRS(DIRB_) {                                                                                                      \
+      real acc[RPL], accW = 0, accE = 0;   /* (unused without residual) */                                                         \
+      if (RL < R && lastw) {                                                                                                       \
+        for (; n >= 2; n -= 2) { BCN_F4_CALL(RL, DIRB_, false) BCN_F4_CALL(RL, !DIRB_, false) itp += 2; }                          \
+      } else {                                                                                                                     \
+        for (; n >= 2; n -= 2) { BCN_F4_CALL(R, DIRB_, false) BCN_F4_CALL(R, !DIRB_, false) itp += 2; }                            \
       }                                                                                                                            \
+    }
+#define BCN_F4_PLAIN1(DIRB_) {                                                                                                     \
+      real acc[RPL], accW = 0, accE = 0;                                                                                           \
+      if (RL < R && lastw) BCN_F4_CALL(RL, DIRB_, false) else BCN_F4_CALL(R, DIRB_, false)                                         \
+      par = DIRB_ ? 0 : 1;                                                                                                         \
+      itp++;                                                                                                                       \
     }
     // Which sweeps evaluate the residual (conv_plan 0: all, as the reference) -- the plans of ns2d_fast2_impl.h:
     //  1 (proven): the increments obey d(k+1) = J d(k) with J symmetric, so log |d(k)|^2 (plain sum of squares) is convex in
@@ -393,52 +499,94 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
       int k_prev = -1, skip_left = 0;
       float l2u_prev = 0, l2w_prev = 0;
       constexpr int JMAX = 256;
-      for (;;) {
-        BCN_F4_SWEEP(true)
-        n_eval++;
-        // the reference tests the sweep count FIRST: a solve that reaches sweep itmax + 1 overflows even if that sweep passes
-        // (rayleigh.py:451-454, in front of the loop condition)
-        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }
-        if (!(err > A.tol)) {
-          if (skip_left > 0) status |= BCN_ST_PLAN;
-          break;
+      // what follows an evaluated sweep: the stop / overflow tests, then the number n of sweeps that need no residual
+#define BCN_F4_AFTER_EVAL(EVEN)                                                                                                    \
+        n_eval++;                                                                                                                  \
+        /* the reference tests the sweep count FIRST: a solve that reaches sweep itmax + 1 overflows even if that sweep passes */  \
+        /* (rayleigh.py:451-454, in front of the loop condition) */                                                                \
+        if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }                                                                      \
+        if (!(err > A.tol)) {                                                                                                      \
+          if (skip_left > 0) status |= BCN_ST_PLAN;                                                                                \
+          break;                                                                                                                   \
+        }                                                                                                                          \
+        n = 0;                                                                                                                     \
+        if (skip_left > 0) {                                                                                                       \
+          skip_left--;                                                                                                             \
+        } else if (plan > 0) {                                                                                                     \
+          const float l2u = __log2f((float)eU), l2w = __log2f((float)err);                                                         \
+          int j = 0;                                                                                                               \
+          if (k_prev >= 0) {                                                                                                       \
+            const float rg = 1.f / (float)(itp - 1 - k_prev);                                                                      \
+            if (plan == 1) {                                                                                                       \
+              const float room = l2u - l2tol_u, rho = (l2u - l2u_prev) * rg;                                                       \
+              if (room > 0.f) j = (rho < 0.f) ? (int)fminf(room / -rho, (float)JMAX) : JMAX;                                       \
+            } else {                                                                                                               \
+              const float room = l2w - l2tol_w, rho = (l2w - l2w_prev) * rg;                                                       \
+              int jw = 0;                                                                                                          \
+              if (room > 0.f) jw = (rho < 0.f) ? (int)fminf(room / -rho, (float)JMAX) : JMAX;                                      \
+              j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                                                           \
+              j = j > 0 ? j : 0;                                                                                                   \
+            }                                                                                                                      \
+          }                                                                                                                        \
+          j = __builtin_amdgcn_readfirstlane(j);                                                                                   \
+          l2u_prev = l2u; l2w_prev = l2w;                                                                                          \
+          k_prev = itp - 1;                                                                                                        \
+          if (A.verify_conv) skip_left = j; else n = j;                                                                            \
+        }                                                                                                                          \
+        if (n > A.itmax - itp) n = A.itmax - itp > 0 ? A.itmax - itp : 0;   /* the overflow test sits in the evaluated sweeps */   \
+        if (EVEN) n &= ~1;   /* pairs only (one evaluation earlier than planned changes no result): the evaluated sweeps */       \
+                             /* then alternate X -> Y, Y -> X whatever n is: every sweep's direction is a compile-time fact */
+      int n = 0;
+      // Two shapes of the loop, picked by what measured faster (the register allocation of the evaluated sweeps decides;
+      // mixing 100x200 float32: 63.4 against 67.6 ms; rayleigh 50x150 float64, every sweep evaluated: 27.9 against 27.2 ms):
+      // float64: directions known at compile time, an even number of plain sweeps between two evaluations;
+      // float32: the direction of an evaluated sweep dispatched on the parity, any number of plain sweeps -- the odd ones
+      //          around the pairs.  A barrier closes every run of plain sweeps: the last one's late edge column, for the
+      //          evaluated sweep that follows.
+      if constexpr (BCN_F4_STATIC_DIR(real)) {
+        for (;;) {
+          BCN_F4_EVAL(false)
+          BCN_F4_AFTER_EVAL(true)
+          BCN_F4_PH(3)
+          if (n > 0) { BCN_F4_PAIRS(true) __syncthreads(); }
+          BCN_F4_PH(2)   // (stamps: phase 2 = the sweeps without residual, phase 3 = the evaluated ones)
+          BCN_F4_EVAL(true)
+          BCN_F4_AFTER_EVAL(true)
+          BCN_F4_PH(3)
+          if (n > 0) { BCN_F4_PAIRS(false) __syncthreads(); }
+          BCN_F4_PH(2)
         }
-        int n = 0;
-        if (skip_left > 0) {
-          skip_left--;
-        } else if (plan > 0) {
-          const float l2u = __log2f((float)eU), l2w = __log2f((float)err);
-          int j = 0;
-          if (k_prev >= 0) {
-            const float rg = 1.f / (float)(itp - 1 - k_prev);
-            if (plan == 1) {
-              const float room = l2u - l2tol_u, rho = (l2u - l2u_prev) * rg;
-              if (room > 0.f) j = (rho < 0.f) ? (int)fminf(room / -rho, (float)JMAX) : JMAX;
-            } else {
-              const float room = l2w - l2tol_w, rho = (l2w - l2w_prev) * rg;
-              int jw = 0;
-              if (room > 0.f) jw = (rho < 0.f) ? (int)fminf(room / -rho, (float)JMAX) : JMAX;
-              j = jw - 1 - (jw >> 4) + A.plan_overshoot;
-              j = j > 0 ? j : 0;
-            }
+      } else {
+        for (;;) {
+          if (par) BCN_F4_EVAL(true) else BCN_F4_EVAL(false)
+          BCN_F4_AFTER_EVAL(false)
+          BCN_F4_PH(3)
+          if (n > 0) {
+            if (par) { BCN_F4_PLAIN1(true) n--; }
+            BCN_F4_PAIRS(false)
+            if (n > 0) BCN_F4_PLAIN1(false)
+            __syncthreads();
           }
-          j = __builtin_amdgcn_readfirstlane(j);
-          l2u_prev = l2u; l2w_prev = l2w;
-          k_prev = itp - 1;
-          if (A.verify_conv) skip_left = j; else n = j;
+          BCN_F4_PH(2)
         }
-        if (n > A.itmax - itp) n = A.itmax - itp > 0 ? A.itmax - itp : 0;   // the overflow test sits in the evaluated sweeps
-        BCN_F4_PH(3)
-        for (; n > 0; n--) BCN_F4_SWEEP(false)
-        BCN_F4_PH(2)   // (stamps: phase 2 = the sweeps without residual, phase 3 = the evaluated ones)
       }
+#undef BCN_F4_AFTER_EVAL
       const bool late = plan >= 2 && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
       if (late) n_late++;
       if (!(late && A.conv_plan == 3)) break;
       plan = 1;
       n_redo++;
     }
-#undef BCN_F4_SWEEP
+#undef BCN_F4_PAIRS
+#undef BCN_F4_PLAIN1
+#undef BCN_F4_EVAL
+#undef BCN_F4_CALL
+    if (par) {   // state Y (column k in slot k + 1): back home
+#pragma unroll
+      for (int k = 0; k < R; k++)
+#pragma unroll
+        for (int r = 0; r < RPL; r++) Pv[k][r] = Pv[k + 1][r];
+    }
     t_jac += __builtin_amdgcn_s_memtime() - tj0;
     BCN_F4_PH(3)
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
@@ -513,12 +661,13 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         const int len = jb1 - jb0;
         real x[CPL], a_c[CPL], y_c[CPL], z_c[CPL], a_n[CPL], y_n[CPL], z_n[CPL];
         int t[CPL], idx[CPL], sel_c[CPL], sel_n[CPL];
-        bool ok_c[CPL], ok_n[CPL];
-        auto fetch = [&](real* a_, real* y_, real* z_, int* sel_, bool* ok_) {
+        // (whether a column is inside the block on a diagonal is carried as sel != 0 -- an index the walk holds anyway -- not
+        //  as a lane mask: four masks across the loop are eight SGPRs, and when those ran short hipcc kept them as 0 / 1
+        //  in VGPRs at four instructions per use)
+        auto fetch = [&](real* a_, real* y_, real* z_, int* sel_) {
 #pragma unroll
           for (int q = 0; q < CPL; q++) {
-            ok_[q] = (unsigned)t[q] <= (unsigned)len;
-            sel_[q] = ok_[q] ? idx[q] : 0;
+            sel_[q] = ((unsigned)t[q] <= (unsigned)len) ? idx[q] : 0;   // (idx >= 1 inside the block)
             a_[q] = TX[sel_[q]];
             const F4YZ yz = TYZ[sel_[q]];
             y_[q] = yz.y; z_[q] = yz.z;
@@ -533,9 +682,9 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
           t[q] = (i <= NX) ? 1 - i : -(1 << 20);
           idx[q] = t[q] * P + i;
         }
-        fetch(a_c, y_c, z_c, sel_c, ok_c);
-        fetch(a_n, y_n, z_n, sel_n, ok_n);
-        auto advance = [&](real* a_, real* y_, real* z_, int* sel_, bool* ok_) {
+        fetch(a_c, y_c, z_c, sel_c);
+        fetch(a_n, y_n, z_n, sel_n);
+        auto advance = [&](real* a_, real* y_, real* z_, int* sel_) {
           // one diagonal with the coefficients in (a_, y_, z_), which are then refilled for the diagonal after the next
           const real wl = dpp<0x138, 0xf, 0xf, true>(real(0), x[CPL - 1]);   // last column of the lane to the left
           real xn[CPL];
@@ -547,16 +696,16 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
             sel_s[q] = sel_[q];
           }
 #pragma unroll
-          for (int q = 0; q < CPL; q++) x[q] = ok_[q] ? xn[q] : x[q];
-          fetch(a_, y_, z_, sel_, ok_);
+          for (int q = 0; q < CPL; q++) x[q] = (sel_s[q] != 0) ? xn[q] : x[q];
+          fetch(a_, y_, z_, sel_);
 #pragma unroll
           for (int q = 0; q < CPL; q++) TX[sel_s[q]] = xn[q];
         };
         const int nsteps = len + NX;
 #pragma unroll 1
         for (int st = 0; st < nsteps; st += 2) {
-          advance(a_c, y_c, z_c, sel_c, ok_c);
-          advance(a_n, y_n, z_n, sel_n, ok_n);   // (an odd count runs one diagonal past the block: no column is inside it)
+          advance(a_c, y_c, z_c, sel_c);
+          advance(a_n, y_n, z_n, sel_n);   // (an odd count runs one diagonal past the block: no column is inside it)
         }
       }
       __syncthreads();
@@ -579,7 +728,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
 #endif
   }
   if (last_chunk) {
-    ns2d_finish<real, NT>(A, b, u, v, S, status, red);
+    ns2d_finish<real, NT>(A, b, A.u + off, A.v + off, A.S + off, status, red);
   } else if (tid == 0) {
     A.status[b] = status;
   }
@@ -607,6 +756,7 @@ template <typename real, int NX, int NY, int R, int RPL, int KIND, bool EQ>
 int launch_fast4_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   using G = Fast4Geom<NX, NY, R, RPL>;
   const size_t lds = (size_t)G::lds_elems(sizeof(real)) * sizeof(real);
+  if (!f4_fields_ok(a, (size_t)G::NCELL)) return BCN_ERR_UNSUPPORTED;   // (the caller falls back to the generic kernel)
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
   const SchedParams sp = ns2d_sched_params(a);
