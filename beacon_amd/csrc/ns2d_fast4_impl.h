@@ -171,20 +171,35 @@ __device__ __forceinline__ void f4_sweep(real (&Pv)[R + 1][RPL], const real (&Bv
   // that an evaluated sweep finds both halos complete when it starts
   constexpr int PB = EV ? -1 : (RC >= 2) ? (RC / 2 > 1 ? RC / 2 : 1) : (DIRB ? 1 : 0);
   real hf[RPL], hl[RPL];
-  if (PB == 0) __syncthreads();
+#if defined(BCN_F4_NOBAR) || defined(BCN_F4_NOLDS)   // timing experiments only (wrong results): plain sweeps without ...
+#ifdef BCN_F4_NOBAR
+#define BCN_F4_SYNC() if (EV) __syncthreads()
+#else
+#define BCN_F4_SYNC() __syncthreads()
+#endif
+#ifdef BCN_F4_NOLDS
+  constexpr bool XCH = EV;
+#else
+  constexpr bool XCH = true;
+#endif
+#else
+#define BCN_F4_SYNC() __syncthreads()
+  constexpr bool XCH = true;
+#endif
+  if (PB == 0) BCN_F4_SYNC();
 #pragma unroll
-  for (int r = 0; r < RPL; r++) hf[r] = first_rd[r];
+  for (int r = 0; r < RPL; r++) hf[r] = XCH ? first_rd[r] : real(0);
   if (PB <= 0 || PB >= RC) {
 #pragma unroll
-    for (int r = 0; r < RPL; r++) hl[r] = last_rd[r];
+    for (int r = 0; r < RPL; r++) hl[r] = XCH ? last_rd[r] : real(0);
   }
 #pragma unroll
   for (int pos = 0; pos < RC; pos++) {
     const int k = DIRB ? pos : RC - 1 - pos;
     if (pos == PB && PB > 0) {
-      __syncthreads();
+      BCN_F4_SYNC();
 #pragma unroll
-      for (int r = 0; r < RPL; r++) hl[r] = last_rd[r];
+      for (int r = 0; r < RPL; r++) hl[r] = XCH ? last_rd[r] : real(0);
     }
     real cv[RPL], wv[RPL], ev[RPL], out[RPL];
 #pragma unroll
@@ -214,11 +229,12 @@ __device__ __forceinline__ void f4_sweep(real (&Pv)[R + 1][RPL], const real (&Bv
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
       if (DIRB) Pv[k][r] = out[r]; else Pv[k + 1][r] = out[r];
-      if (pos == 0) first_wr[r] = out[r];
-      if (pos == RC - 1) last_wr[r] = out[r];
+      if (XCH && pos == 0) first_wr[r] = out[r];
+      if (XCH && pos == RC - 1) last_wr[r] = out[r];
     }
   }
-  if (PB >= RC) __syncthreads();
+  if (PB >= RC) BCN_F4_SYNC();
+#undef BCN_F4_SYNC
 }
 
 // timesteps [it_begin, it_end) of replica b: the whole action step (plain launch) or one chunk of it (ticket scheduler,
