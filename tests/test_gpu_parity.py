@@ -56,6 +56,7 @@ F32 = {
     ("mix_jit", 2): f32tol(1.2e-6, 1.2e-6, 3e-6, 8e-6, None, 4.5e-7),
     ("mix_jit", "100x130"): f32tol(1.2e-6, 1.2e-6, 3e-6, 8e-6, None, 4.5e-7),
     ("mix_jit", "100x200"): f32tol(7e-6, 4.5e-6, 1.4e-4, 9e-6, None, 4.5e-7),
+    ("mix_jit", "106x200"): f32tol(1.2e-6, 1.2e-6, 2.5e-6, 8.8e-6, None, 3.4e-7),
     ("mix_jit", "200x100"): f32tol(5e-7, 5e-7, 1.7e-6, 8e-6, None, 4.5e-7),
 }
 DEV = "cuda:0"
@@ -992,14 +993,17 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
                                             (2.2, 1.28, "f32", 5e-5), (2.2, 1.28, "f64", F64_TOL), (1.0, 1.4, "f32", 5e-5),
                                             (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL),
                                             (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5),
-                                            (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL), (6.0, 1.0, "f32", 5e-5)])
+                                            (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL), (6.0, 1.0, "f32", 5e-5),
+                                            (1.06, 3.0, "f32", 5e-5)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
     60x120, 110x65 (two rows per lane; odd ny: the last lane holds one row; float64: fields in a global scratch), and
     50x150, 64x200, 50x145, 50x149 (ny > 128: ns2d_fast4_impl.h, the Poisson solve in registers with 3 / 4 rows per lane
     -- the last lane holding 1 or 2 rows where 3 does not divide ny --, the transport as a register walk along anti-diagonals),
-    and 300x50 (too wide for the one-row-per-lane kernel's registers: the same hybrid with one row per lane, 16 strips of 19 columns) -- 30 timesteps with distinct actions against the float64 oracle, and against
+    and 300x50 (too wide for the one-row-per-lane kernel's registers: the same hybrid with one row per lane, 16 strips of 19 columns),
+    and 53x150 (14 strips of 4 columns, the last one a single column: the sweep's barrier placement for that case; 50x149 in
+    float64 is the same case under the other shape of the Jacobi loop) -- 30 timesteps with distinct actions against the float64 oracle, and against
     the generic kernel on the same inputs."""
     B = 6
     env = V.VecRayleigh(B, DEV, dtype, None, L=L, H=H)
@@ -1042,11 +1046,11 @@ def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     env.close()
 
 
-@pytest.mark.parametrize("L,H", [(1.0, 1.1), (1.0, 1.05), (1.0, 2.0), (1.0, 1.3), (2.0, 1.0)])
+@pytest.mark.parametrize("L,H", [(1.0, 1.1), (1.0, 1.05), (1.0, 2.0), (1.0, 1.3), (2.0, 1.0), (1.06, 2.0)])
 def test_jit_grid_mixing_vs_oracle(L, H):
     """mixing(L=1.0, H=1.1 / 1.05): 100x110 / 100x105 (odd ny), two rows per lane, strips of 13 columns (the last wave 9);
     mixing(L=1.0, H=2.0 / 1.3): 100x200 / 100x130, ns2d_fast4_impl.h (15 strips of 7 columns, 4 / 3 rows per lane, transport in
-    two row blocks / one); mixing(L=2.0, H=1.0): 200x100 (wider than the two-rows-per-lane kernel's registers take): the
+    two row blocks / one; L=1.06: 106x200, 16 strips of 7 columns, the last one a single column); mixing(L=2.0, H=1.0): 200x100 (wider than the two-rows-per-lane kernel's registers take): the
     same hybrid with 2 rows per lane, 16 strips of 13 columns, 4 columns per lane in the transport walk;
     40 timesteps from rest."""
     env = V.VecMixing(4, DEV, "f32", L=L, H=H)
