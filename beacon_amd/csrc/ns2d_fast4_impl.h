@@ -253,11 +253,17 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
 #define BCN_F4_STATIC_DIR(real) (sizeof(real) == 8)
 #endif
   constexpr int U = (CPL >= BCN_F4_U) ? 1 : BCN_F4_U / CPL;   // rows of a lane in flight in the HBM/L2 phases
+#ifndef BCN_F4_UP
+#define BCN_F4_UP 2
+#endif
+  constexpr int UP = BCN_F4_UP * U;   // ... in the predictor and the corrector (measured: twice as many pay there, not in the transport)
   const int tid = threadIdx.x;
   const int tx = tid & (BCN_WAVE - 1), w = tid >> 6;
   const size_t off = (size_t)b * G::NCELL;
 
   real* red = reinterpret_cast<real*>(smem);  // [2][2][16]
+  // (the transport walk addresses LDS by integer offsets from 0)
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   real* sact = red + 2 * 32;                  // [64] conditioned actions ([128..129]: the scheduler's words)
   real* hal = red + G::FIXED;                     // Poisson: edge-column exchange
   real* W = hal + G::HAL;                     // Poisson: -rhs in, phi out (natural layout, pitch P)
@@ -383,7 +389,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
     BCN_F4_PH(0)
 
     // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) ----
-    f4_cells<NX, NW, U>(w, tx, 1, NY,
+    f4_cells<NX, NW, UP>(w, tx, 1, NY,
       [&](int j, int i) {
         const int c = j * SX + i;
         F4Pred<real> q;
@@ -616,7 +622,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
     __syncthreads();
 
     // ---- p += phi incl. ghosts (rayleigh.py:219), corrector (rayleigh.py:460-464) ----
-    f4_cells<NX, NW, U>(w, tx, 1, NY,
+    f4_cells<NX, NW, UP>(w, tx, 1, NY,
       [&](int j, int i) {
         const int c = j * SX + i;
         // the ghost cells next to an edge cell take the same increment (an interior cell re-reads itself: no extra traffic)
@@ -676,19 +682,25 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         // keeps its value; the coefficients are fetched two diagonals ahead of their use.
         const int len = jb1 - jb0;
         real x[CPL], a_c[CPL], y_c[CPL], z_c[CPL], a_n[CPL], y_n[CPL], z_n[CPL];
-        int t[CPL], idx[CPL], sel_c[CPL], sel_n[CPL];
-        // (whether a column is inside the block on a diagonal is carried as sel != 0 -- an index the walk holds anyway -- not
+        int t[CPL];
+        unsigned ib[CPL], sel_c[CPL], sel_n[CPL];   // BYTE offsets into TX (twice that into TYZ): no shift per access
+        // (whether a column is inside the block on a diagonal is carried as sel != 0 -- an offset the walk holds anyway -- not
         //  as a lane mask: four masks across the loop are eight SGPRs, and when those ran short hipcc kept them as 0 / 1
         //  in VGPRs at four instructions per use)
-        auto fetch = [&](real* a_, real* y_, real* z_, int* sel_) {
+        // LDS addresses as integers (the kernel's shared memory is all dynamic and starts at 0 -- checked where the kernel
+        // starts): through `smem + ...` hipcc adds the array's base symbol, a literal 0, to every address in the walk
+        typedef __attribute__((address_space(3))) real lds_real;
+        constexpr unsigned TX0 = (unsigned)(G::FIXED * sizeof(real));
+        constexpr unsigned TYZ0 = TX0 + (unsigned)(((BR * P + 1) & ~1) * sizeof(real));
+        auto fetch = [&](real* a_, real* y_, real* z_, unsigned* sel_) {
 #pragma unroll
           for (int q = 0; q < CPL; q++) {
-            sel_[q] = ((unsigned)t[q] <= (unsigned)len) ? idx[q] : 0;   // (idx >= 1 inside the block)
-            a_[q] = TX[sel_[q]];
-            const F4YZ yz = TYZ[sel_[q]];
-            y_[q] = yz.y; z_[q] = yz.z;
+            sel_[q] = ((unsigned)t[q] <= (unsigned)len) ? ib[q] : 0u;   // (cell index >= 1 inside the block)
+            a_[q] = *reinterpret_cast<lds_real*>(TX0 + sel_[q]);
+            const lds_real* yz = reinterpret_cast<lds_real*>(TYZ0 + 2u * sel_[q]);   // (one 64-bit access: F4YZ is aligned)
+            y_[q] = yz[0]; z_[q] = yz[1];
             t[q] += 1;
-            idx[q] += P;
+            ib[q] += (unsigned)(P * sizeof(real));
           }
         };
 #pragma unroll
@@ -696,26 +708,26 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
           const int i = tx * CPL + 1 + q;
           x[q] = (i <= NX) ? S[(jb0 - 1) * SX + i] : real(0);   // row below the block: the south ghost or the rows done before
           t[q] = (i <= NX) ? 1 - i : -(1 << 20);
-          idx[q] = t[q] * P + i;
+          ib[q] = (unsigned)((t[q] * P + i) * (int)sizeof(real));
         }
         fetch(a_c, y_c, z_c, sel_c);
         fetch(a_n, y_n, z_n, sel_n);
-        auto advance = [&](real* a_, real* y_, real* z_, int* sel_) {
+        auto advance = [&](real* a_, real* y_, real* z_, unsigned* sel_) {
           // one diagonal with the coefficients in (a_, y_, z_), which are then refilled for the diagonal after the next
           const real wl = dpp<0x138, 0xf, 0xf, true>(real(0), x[CPL - 1]);   // last column of the lane to the left
           real xn[CPL];
-          int sel_s[CPL];
 #pragma unroll
           for (int q = 0; q < CPL; q++) {
             const real wv = (q == 0) ? wl : x[q - 1];
             xn[q] = z_[q] * x[q] + (y_[q] * wv + a_[q]);
-            sel_s[q] = sel_[q];
           }
 #pragma unroll
-          for (int q = 0; q < CPL; q++) x[q] = (sel_s[q] != 0) ? xn[q] : x[q];
+          for (int q = 0; q < CPL; q++) {
+            x[q] = (sel_[q] != 0) ? xn[q] : x[q];
+            // (stored BEFORE the refill: the registers of a_ and sel_ are free for it -- no copies at the loop's end)
+            *reinterpret_cast<lds_real*>(TX0 + sel_[q]) = xn[q];
+          }
           fetch(a_, y_, z_, sel_);
-#pragma unroll
-          for (int q = 0; q < CPL; q++) TX[sel_s[q]] = xn[q];
         };
         const int nsteps = len + NX;
 #pragma unroll 1
