@@ -11,11 +11,15 @@
 //  * Poisson: wave w owns the column strip [w R + 1, w R + R], lane l the rows [l RPL + 1, (l+1) RPL], RPL = ceil(ny / 64)
 //    (rows past ny in the last lane hold zeros): the vertical neighbours of a cell are in the lane's own registers except
 //    across lanes (one DPP move up, one down per COLUMN), the horizontal ones in the wave's own registers except at the
-//    strip edges, which go through LDS once per sweep (RPL contiguous values per lane, one barrier per sweep).  The
-//    residual of the reference's stop test (sum over the whole array incl. ghosts, rayleigh.py:448-449) is evaluated where
-//    the plan says the test can pass (conv_plan 0: every sweep, as the reference; 1 proven, 2 extrapolated, 3 extrapolated
-//    and guarded -- as in ns2d_fast2_impl.h); its workgroup reduction shares the barrier of the edge exchange.  Up to 16
-//    waves of <= 128 VGPRs: four per SIMD hide each other's DPP / LDS latencies (8 fatter waves measured slower).
+//    strip edges, which go through LDS once per sweep (RPL contiguous values per lane).  A sweep copies nothing: the R
+//    columns live in R + 1 register slots and shift by one slot per sweep, east -> west and back (f4_sweep); the barrier of
+//    the edge exchange sits in mid-sweep, so that neither an LDS latency nor the barrier's skew is exposed between two
+//    sweeps.  The residual of the reference's stop test (sum over the whole array incl. ghosts, rayleigh.py:448-449) is
+//    evaluated where the plan says the test can pass (conv_plan 0: every sweep, as the reference; 1 proven, 2 extrapolated,
+//    3 extrapolated and guarded -- as in ns2d_fast2_impl.h); an evaluated sweep ends with the barrier of its workgroup
+//    reduction.  Up to 16 waves of <= 128 VGPRs: four per SIMD (8 fatter waves measured slower).
+//  * the fields are addressed through ONE buffer descriptor (the host lays them out as [6][B][ncell]) with an SGPR offset
+//    per field and one 32-bit offset per lane (F4Field): 64-bit addresses per lane and field did not fit the 128 registers.
 //  * the reference's IN-PLACE transport sweep (rayleigh.py:468-487): S' = A + aW S'(i-1,j) + aS S'(i,j-1).  A, aW, aS are
 //    computed by all waves into LDS (as many rows at a time as fit: two blocks at 100x200 float32); then ONE wave walks
 //    the anti-diagonals d = i + j with lanes along x: the west value is the neighbouring lane's previous result (one

@@ -38,6 +38,9 @@ ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 for name, mk, act in (("mixing 100x200", lambda: VecMixing(B, dtype=torch.float32, L=1.0, H=2.0), lambda e: (torch.arange(B, dtype=torch.int32, device="cuda") % 4)),
                       ("rayleigh 50x150", lambda: VecRayleigh(B, dtype=torch.float32, L=1.0, H=3.0), lambda e: torch.zeros(B, e.n_sgts, dtype=torch.float32, device="cuda")),
                       ("rayleigh 50x150 f64", lambda: VecRayleigh(B, dtype=torch.float64, L=1.0, H=3.0), lambda e: torch.zeros(B, e.n_sgts, dtype=torch.float64, device="cuda")),
+                      ("mixing 200x100", lambda: VecMixing(B, dtype=torch.float32, L=2.0, H=1.0), lambda e: (torch.arange(B, dtype=torch.int32, device="cuda") % 4)),
+                      ("rayleigh 300x50", lambda: VecRayleigh(B, dtype=torch.float32, L=6.0, H=1.0), lambda e: torch.zeros(B, e.n_sgts, dtype=torch.float32, device="cuda")),
+                      ("rayleigh 110x64 f64", lambda: VecRayleigh(B, dtype=torch.float64, L=2.2, H=1.28), lambda e: torch.zeros(B, e.n_sgts, dtype=torch.float64, device="cuda")),
                       ("mixing 100x100", lambda: VecMixing(B, dtype=torch.float32), lambda e: torch.zeros(B, dtype=torch.int32, device="cuda"))):
     if ONLY not in name:
         continue
