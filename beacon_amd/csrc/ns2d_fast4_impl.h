@@ -197,45 +197,115 @@ __device__ __forceinline__ void f4_sweep(real (&Pv)[R + 1][RPL], const real (&Bv
 #pragma unroll
     for (int r = 0; r < RPL; r++) hl[r] = XCH ? last_rd[r] : real(0);
   }
+  // A column's cells STAGE BY STAGE (e + w of all of them, then n + s, the sum, the fma) with scheduling barriers in
+  // between: left to itself hipcc emits a cell as add, add, add, fma on the registers just written, and the dependent
+  // instructions cost more issue time than the four waves of a SIMD hide (plain sweep of 7 x 4 cells: 2 196 cycles cell by
+  // cell, 1 916 a column at a time; scripts/sweep_cost.py).  With four rows per lane, that is: with three the two orders
+  // measure the same, with two a stage is four columns (200x100: 63.9 ms; 66.4 a column at a time or unstaged), and with
+  // one row per lane the scheduler keeps its freedom (300x50: 38.7 ms; 40.5 / 39.2 / 39.6 staged by 1 / 2 / 4 columns).
+  // All reads of a group precede its writes.
+#ifndef BCN_F4_GROUP   // columns per stage
+#define BCN_F4_GROUP(RPL) ((RPL) == 2 ? 4 : 1)
+#endif
+#ifndef BCN_F4_STAGE_ROWS
+#define BCN_F4_STAGE_ROWS 2
+#endif
+  constexpr bool STAGED = RPL >= BCN_F4_STAGE_ROWS;
+  constexpr int G = (STAGED && RC >= 2 * BCN_F4_GROUP(RPL)) ? BCN_F4_GROUP(RPL) : 1;
+  constexpr int PBG = (PB > 0 && PB < RC) ? ((PB + G - 1) / G) * G : PB;   // the barrier, moved to the next group boundary
+  static_assert(!(PB > 0 && PB < RC) || (PBG >= 1 && PBG <= ((RC - 1) / G) * G), "barrier between the first and the last column");
 #pragma unroll
-  for (int pos = 0; pos < RC; pos++) {
-    const int k = DIRB ? pos : RC - 1 - pos;
-    if (pos == PB && PB > 0) {
+  for (int pos0 = 0; pos0 < RC; pos0 += G) {
+    if (pos0 == PBG && PBG > 0 && PBG < RC) {
       BCN_F4_SYNC();
 #pragma unroll
       for (int r = 0; r < RPL; r++) hl[r] = XCH ? last_rd[r] : real(0);
     }
-    real cv[RPL], wv[RPL], ev[RPL], out[RPL];
+    real cv[G][RPL], hs[G][RPL], vs_[G][RPL], out[G][RPL];
+    // stage 1: e + w, and the lane-crossing neighbours of each column
+    real sdn[G], nup[G];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-      cv[r] = DIRB ? Pv[k + 1][r] : Pv[k][r];
-      if (k == 0) wv[r] = DIRB ? hf[r] : hl[r];
-      else wv[r] = DIRB ? Pv[k][r] : Pv[k > 0 ? k - 1 : 0][r];
-      if (k == RC - 1) ev[r] = DIRB ? hl[r] : hf[r];
-      else ev[r] = DIRB ? Pv[k + 2 <= R ? k + 2 : R][r] : Pv[k + 1][r];
-    }
-    const real sdn = from_below<real>(cv[0], cv[RPL - 1]);
-    const real nup = dpp<0x130, 0xf, 0xf, true>(real(0), cv[0]);
+    for (int g = 0; g < G; g++) {
+      const int pos = pos0 + g;
+      if (pos < RC) {
+        const int k = DIRB ? pos : RC - 1 - pos;
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-      const real s = (r == 0) ? sdn : cv[r > 0 ? r - 1 : 0];
-      real n = (r == RPL - 1) ? nup : cv[r + 1 < RPL ? r + 1 : r];
-      if (KIND == 0 && r == RT) n = tmask * cv[r] + n;
-      if constexpr (EQ) out[r] = cxr[r] * ((ev[r] + wv[r]) + (n + s)) + Bv[k][r];
-      else out[r] = cyr[r] * (n + s) + (cxr[r] * (ev[r] + wv[r]) + Bv[k][r]);
-      if (EV) {
-        const real d = out[r] - cv[r];
-        acc[r] += d * d;
-        if (k == 0) accW += d * d;
-        if (k == RC - 1) accE += d * d;
+        for (int r = 0; r < RPL; r++) {
+          cv[g][r] = DIRB ? Pv[k + 1][r] : Pv[k][r];
+          real wv, ev;
+          if (k == 0) wv = DIRB ? hf[r] : hl[r];
+          else wv = DIRB ? Pv[k][r] : Pv[k > 0 ? k - 1 : 0][r];
+          if (k == RC - 1) ev = DIRB ? hl[r] : hf[r];
+          else ev = DIRB ? Pv[k + 2 <= R ? k + 2 : R][r] : Pv[k + 1][r];
+          hs[g][r] = ev + wv;
+        }
+        sdn[g] = from_below<real>(cv[g][0], cv[g][RPL - 1]);
+        nup[g] = dpp<0x130, 0xf, 0xf, true>(real(0), cv[g][0]);
       }
     }
+    if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
+    // stage 2: n + s
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-      if (DIRB) Pv[k][r] = out[r]; else Pv[k + 1][r] = out[r];
-      if (XCH && pos == 0) first_wr[r] = out[r];
-      if (XCH && pos == RC - 1) last_wr[r] = out[r];
+    for (int g = 0; g < G; g++)
+      if (pos0 + g < RC) {
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+          const real s = (r == 0) ? sdn[g] : cv[g][r > 0 ? r - 1 : 0];
+          real n = (r == RPL - 1) ? nup[g] : cv[g][r + 1 < RPL ? r + 1 : r];
+          if (KIND == 0 && r == RT) n = tmask * cv[g][r] + n;
+          vs_[g][r] = n + s;
+        }
+      }
+    if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
+    // stage 3: (e + w) + (n + s), or the inner fma where dx != dy
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      if (pos0 + g < RC) {
+        const int k = DIRB ? pos0 + g : RC - 1 - (pos0 + g);
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+          if constexpr (EQ) hs[g][r] = hs[g][r] + vs_[g][r];
+          else hs[g][r] = cxr[r] * hs[g][r] + Bv[k][r];
+        }
+      }
+    if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
+    // stage 4: the new values
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      if (pos0 + g < RC) {
+        const int k = DIRB ? pos0 + g : RC - 1 - (pos0 + g);
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+          if constexpr (EQ) out[g][r] = cxr[r] * hs[g][r] + Bv[k][r];
+          else out[g][r] = cyr[r] * vs_[g][r] + hs[g][r];
+        }
+      }
+    if constexpr (STAGED) __builtin_amdgcn_sched_barrier(0);
+    if (EV) {
+#pragma unroll
+      for (int g = 0; g < G; g++)
+        if (pos0 + g < RC) {
+          const int k = DIRB ? pos0 + g : RC - 1 - (pos0 + g);
+#pragma unroll
+          for (int r = 0; r < RPL; r++) {
+            const real d = out[g][r] - cv[g][r];
+            acc[r] += d * d;
+            if (k == 0) accW += d * d;
+            if (k == RC - 1) accE += d * d;
+          }
+        }
     }
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      if (pos0 + g < RC) {
+        const int pos = pos0 + g, k = DIRB ? pos : RC - 1 - pos;
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+          if (DIRB) Pv[k][r] = out[g][r]; else Pv[k + 1][r] = out[g][r];
+          if (XCH && pos == 0) first_wr[r] = out[g][r];
+          if (XCH && pos == RC - 1) last_wr[r] = out[g][r];
+        }
+      }
   }
   if (PB >= RC) BCN_F4_SYNC();
 #undef BCN_F4_SYNC
