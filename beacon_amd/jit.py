@@ -200,7 +200,7 @@ TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 6
               (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
               (100, 105, False, 1), (50, 70, True, 0), (50, 150, False, 0), (50, 150, True, 0), (64, 200, False, 0),
               (100, 200, False, 1), (50, 145, False, 0), (50, 149, True, 0), (100, 130, False, 1),
-              (300, 50, False, 0), (200, 100, False, 1)]
+              (300, 50, False, 0), (200, 100, False, 1), (53, 150, False, 0), (106, 200, False, 1)]
 
 
 def prebuild(grids=None, verbose=False):
