@@ -64,9 +64,16 @@ struct Fast2Geom {
 // west values in registers, the south value of the lower row from the lane below (its upper row of
 // the previous step) and the explicit part A, u, v prefetched PD steps ahead from LDS.  Lanes outside
 // the domain compute on clamped addresses and write to `dummy`.
-template <typename real, int NX, int NY, int PD>
-__device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real* Ul, const real* Vl, real* dummy,
+// GLB: the fields (and `dummy`) are in global memory -- as GLOBAL pointers: as generic pointers of this out-of-line function
+// every access was a flat_load / flat_store, which count on both wait counters and cost 64-bit address arithmetic
+template <typename real, int NX, int NY, int PD, bool GLB>
+__device__ __attribute__((noinline)) void transport_chain2(real* Tl_, const real* Ul_, const real* Vl_, real* dummy_,
                                                            real c0x, real c1x, real c0y, real c1y) {
+  typedef typename std::conditional<GLB, __attribute__((address_space(1))) real, real>::type freal;
+  freal* const Tl = (freal*)Tl_;
+  const freal* const Ul = (const freal*)Ul_;
+  const freal* const Vl = (const freal*)Vl_;
+  freal* const dummy = (freal*)dummy_;
   constexpr int SY = NY + 2, SZ = (NX + 2) * SY, LH = (NY + 1) / 2;   // PD: steps of prefetch (4 from LDS, more from global memory)
   constexpr bool ODD = (NY & 1) != 0;
   constexpr int NSTEP = NX + LH - 1;
@@ -96,9 +103,9 @@ __device__ __attribute__((noinline)) void transport_chain2(real* Tl, const real*
       const bool ok = active && lane <= t && lane > t - NX;
       tp0 = ok ? tn0 : tp0;
       tp1 = ok ? tn1 : tp1;
-      real* dst = ok ? Tl + (cb + t * SY) : dummy;
+      freal* dst = ok ? Tl + (cb + t * SY) : dummy;
       dst[0] = tn0;
-      if (ODD) { real* d1 = (ok && lane < LH - 1) ? dst : dummy; d1[1] = tn1; }   // odd ny: the last lane has no upper row
+      if (ODD) { freal* d1 = (ok && lane < LH - 1) ? dst : dummy; d1[1] = tn1; }   // odd ny: the last lane has no upper row
       else dst[1] = tn1;
       const int x = at(t + PD);
       a0[q] = Tl[x]; a1[q] = Tl[x + 1]; g[q] = Tl[x - 1];
@@ -757,7 +764,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       if constexpr (std::is_same<real, float>::value && GF == 0)
         transport_chain2_f32<NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2, real(0.5) * dt * rdy);
       else
-        transport_chain2<real, NX, NY, (GF ? BCN_PDG2 : 4)>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
+        transport_chain2<real, NX, NY, (GF ? BCN_PDG2 : 4), (GF != 0)>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx,
                                        dt * A.ksc * rdy2, real(0.5) * dt * rdy);
     }
     __syncthreads();

@@ -225,10 +225,26 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
   const int j = lane + 1;
   const bool active = lane < NY;
   const int cb = (1 - lane) * SY + j;
-  real* Tb = Tl + cb;
+#ifndef BCN_CHAIN_FLAT
+  // T in the global scratch (GF): as a GLOBAL pointer, and the masked lanes' sink in the scratch's front pad.  As generic
+  // pointers of this out-of-line function (and with an LDS sink selected against a global address) every access of T was a
+  // flat_load / flat_store: those count on BOTH wait counters, so the waits of the u, v reads from LDS also waited for the
+  // prefetch of T.
+  typedef typename std::conditional<GF != 0, __attribute__((address_space(1))) real, real>::type treal;
+  treal* const Tb = (treal*)(Tl + cb);
+  treal* const dummy_t = GF != 0 ? (treal*)(Tl - G::FRONTG) : (treal*)dummy;
+#else
+  typedef real treal;
+  real* const Tb = Tl + cb;
+  real* const dummy_t = dummy;
+#endif
   // u, v without pads (GF == 2): lanes outside the domain read a clamped index (their values are masked)
-  auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ul[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ul[x]; };
-  auto ldv = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Vl[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Vl[x]; };
+  // (u, v: global with GF == 1, LDS otherwise)
+  typedef typename std::conditional<GF == 1, __attribute__((address_space(1))) real, real>::type ureal;
+  const ureal* const Ug = (const ureal*)Ul;
+  const ureal* const Vg = (const ureal*)Vl;
+  auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ug[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ug[x]; };
+  auto ldv = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Vg[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Vg[x]; };
   real ra[PD], ru[PD], rv[PD], rg[PD];
 #pragma unroll
   for (int q = 0; q < PD; q++) { ra[q] = Tb[q * SY]; ru[q] = ldu(q); rv[q] = ldv(q); rg[q] = Tb[q * SY - 1]; }
@@ -248,7 +264,7 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
         const bool ok = active && (MASK != 2 ? (lane <= t) : true) &&                       \
                         (MASK != 1 ? (lane > t - NX && t < NSTEP) : true);                  \
         tp = ok ? tn : tp;                                                                  \
-        real* dst = ok ? Tb + t * SY : dummy;                                               \
+        treal* dst = ok ? Tb + t * SY : dummy_t;                                            \
         *dst = tn;                                                                          \
       }                                                                                     \
       ra[q] = Tb[(t + PD) * SY];                                                            \
