@@ -41,7 +41,9 @@
 #define BCN_GFD 2   // float64 128x64: 1 = u, v, T in global scratch, 2 = u, v in LDS and T in global scratch
 #endif
 #ifndef BCN_PDG
-#define BCN_PDG 12   // global fields: 4 / 8 / 12 diagonals ahead: 52.9 / 52.1 / 51.3 ms per step (rayleigh 128x64 float64)
+#define BCN_PDG 8    // global fields, diagonals ahead.  Round 3 (T through flat pointers): 4 / 8 / 12 -> 52.9 / 52.1 / 51.3 ms per step
+                     // (rayleigh 128x64 float64); round 4 (global pointers): 4 / 8 / 10 / 12 / 16 / 20 -> 53.0 / 51.2 / 51.9 / 52.0 / 51.9 / 61.0.
+                     // (6 is NOT a valid depth: the solve stopped converging -- unexplained; use the measured values only)
 #endif
 #ifndef BCN_PDF
 #define BCN_PDF 8    // fields in LDS: diagonals per block of the transport wave (two register sets: it runs PDF..2 PDF diagonals ahead;
@@ -226,21 +228,21 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
   const bool active = lane < NY;
   const int cb = (1 - lane) * SY + j;
 #ifndef BCN_CHAIN_FLAT
-  // T in the global scratch (GF): as a GLOBAL pointer, and the masked lanes' sink in the scratch's front pad.  As generic
-  // pointers of this out-of-line function (and with an LDS sink selected against a global address) every access of T was a
-  // flat_load / flat_store: those count on BOTH wait counters, so the waits of the u, v reads from LDS also waited for the
-  // prefetch of T.
-  typedef typename std::conditional<GF != 0, __attribute__((address_space(1))) real, real>::type treal;
+  // Every field through a pointer of its OWN address space -- T: LDS (GF == 0) or the global scratch (the masked lanes' sink
+  // then lies in the scratch's front pad); u, v: the global scratch with GF == 1, LDS otherwise.  As generic pointers of this
+  // out-of-line function every access of the global scratch was a flat_load / flat_store, which count on BOTH wait counters
+  // (the waits of the LDS reads also waited for the prefetch of T), and every LDS access paid a 64-bit add and a
+  // null-checked address-space conversion.
+  typedef typename std::conditional<GF != 0, __attribute__((address_space(1))) real, __attribute__((address_space(3))) real>::type treal;
+  typedef typename std::conditional<GF == 1, __attribute__((address_space(1))) real, __attribute__((address_space(3))) real>::type ureal;
   treal* const Tb = (treal*)(Tl + cb);
   treal* const dummy_t = GF != 0 ? (treal*)(Tl - G::FRONTG) : (treal*)dummy;
 #else
   typedef real treal;
+  typedef real ureal;
   real* const Tb = Tl + cb;
   real* const dummy_t = dummy;
 #endif
-  // u, v without pads (GF == 2): lanes outside the domain read a clamped index (their values are masked)
-  // (u, v: global with GF == 1, LDS otherwise)
-  typedef typename std::conditional<GF == 1, __attribute__((address_space(1))) real, real>::type ureal;
   const ureal* const Ug = (const ureal*)Ul;
   const ureal* const Vg = (const ureal*)Vl;
   auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ug[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ug[x]; };

@@ -86,7 +86,7 @@ def choose(nx, ny, f64, kind):
             # converging in its third timestep after a semantically neutral reordering of two tests in the Jacobi loop
             # (round 4; column 99, the narrow strip's first one; root cause not found): such grids take the hybrid kernel
             # of ns2d_fast4_impl.h (below) instead
-            if f64 and (rl != r or r > 16):
+            if f64 and (rl != r or r > 16) and os.environ.get("BEACON_JIT_F64_TWOBODY") != "1":   # (the switch: experiments)
                 continue
             for gf in ((0,) if not f64 else (2, 1)):
                 if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
