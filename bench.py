@@ -701,12 +701,14 @@ def main():
                          "late_stops_last_step": int(cyc[:, 2].sum()), "repeated_timesteps_last_step": int(cyc[:, 3].sum())}
         if strong is not None:
             out["strong"] = strong
+        # (the N > 1 rehearsal BEFORE the CPU legs: the C oracle's OpenMP workers keep spinning on every host core after
+        #  their parallel regions, and the blocking gather's host side then measured 2 ms per step late)
+        sec = []
+        if world == 1 and not args.no_secondary and not args.stub and not distc:
+            sec = dist_path_lines()
         if world == 1 and not args.no_cpu and not args.stub:
             out["cpu_baseline"] = cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H))
         if world == 1 and not args.no_secondary and not args.stub:
-            sec = []
-            if not distc:
-                sec = dist_path_lines()
             env.close()
             sec += secondary_lines(dev, acts_np, W, init, (L, H))
             out["secondary"] = sec
