@@ -426,6 +426,10 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
   constexpr int HPAR = NW * 2 * HROWS;
 
   int status = first_chunk ? 0 : A.status[b];   // a replica that overflowed stays stopped (status is never NULL: capi.hip)
+  // sweeps of the previous timestep's solve (wave-uniform; 0: unknown): where a solve under an extrapolating plan opens
+  // (spec_start, as in ns2d_fast_impl.h)
+  int prev_itp = (it_begin > 0 && A.sweeps) ? __builtin_amdgcn_readfirstlane(A.sweeps[(size_t)b * A.ndt_act + it_begin - 1]) : 0;
+  int prev2_itp = (it_begin > 1 && A.sweeps) ? __builtin_amdgcn_readfirstlane(A.sweeps[(size_t)b * A.ndt_act + it_begin - 2]) : 0;
   for (int it = it_begin; it < it_end && status == 0; it++) {
     // ---- boundary conditions (rayleigh.py:180-202 / mixing.py:153-171) ----
     BCN_F4_PH(7)
@@ -633,6 +637,24 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         if (EVEN) n &= ~1;   /* pairs only (one evaluation earlier than planned changes no result): the evaluated sweeps */       \
                              /* then alternate X -> Y, Y -> X whatever n is: every sweep's direction is a compile-time fact */
       int n = 0;
+      // Speculative opening (spec_start > 0, extrapolating plans): with the previous timestep's count to go by, the solve
+      // opens with plain sweeps up to spec_start / 8 of it and evaluates the residual there for the first time -- sweeps 1
+      // and 2, evaluated only to start the plan, are two of a solve's eight evaluations.  If that first evaluation fails,
+      // no earlier sweep passed; if it passes, the guess was too far and the solve is repeated without it, under the same plan
+      // (whatever the plan: the results never depend on spec_start).
+      bool spec_open = false;
+      // (the smaller of the last TWO counts: one solve that took long -- the first after an action, a spike in a flow at
+      //  rest -- is followed by short ones, and a guess from it costs a whole solve)
+      const int prev_min = prev_itp < prev2_itp ? prev_itp : prev2_itp;
+      // (compiled in where it measured a gain: rayleigh float32 with >= 2 rows per lane, 50x150 12.7 -> 12.2 ms; its mere
+      //  presence cost mixing 100x200 2.4 % and rayleigh 300x50 6 % -- code size -- and mixing's counts drop too fast after an
+      //  action for any guess: 60.1 -> 66.1 / 73.0 ms at spec_start 6 / 7)
+      constexpr bool SPEC_OPEN = KIND == 0 && RPL >= 2 && std::is_same<real, float>::value;
+      if (SPEC_OPEN && A.spec_start > 0 && plan > 1 && !A.verify_conv && prev_min >= 16) {
+        n = ((prev_min * A.spec_start) >> 3) & ~1;
+        if (n > A.itmax) n = A.itmax & ~1;
+        if (n > 0) { spec_open = true; BCN_F4_PAIRS(false) __syncthreads(); }
+      }
       // Two shapes of the loop, picked by what measured faster (the register allocation of the evaluated sweeps decides;
       // mixing 100x200 float32: 63.4 against 67.6 ms; rayleigh 50x150 float64, every sweep evaluated: 27.9 against 27.2 ms):
       // float64: directions known at compile time, an even number of plain sweeps between two evaluations;
@@ -667,6 +689,10 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         }
       }
 #undef BCN_F4_AFTER_EVAL
+      if (spec_open && k_prev < 0 && !(status & BCN_ST_ITMAX)) {   // the opening's first evaluation passed: too far
+        prev_itp = 0;
+        continue;
+      }
       const bool late = plan >= 2 && itp >= 2 && k_prev != itp - 2 && !(status & BCN_ST_ITMAX);
       if (late) n_late++;
       if (!(late && A.conv_plan == 3)) break;
@@ -686,6 +712,8 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
     t_jac += __builtin_amdgcn_s_memtime() - tj0;
     BCN_F4_PH(3)
     if (A.sweeps && tid == 0) A.sweeps[(size_t)b * A.ndt_act + it] = itp;
+    prev2_itp = prev_itp;
+    prev_itp = (status & BCN_ST_ITMAX) ? 0 : itp;
 
     // phi -> LDS (natural layout): the corrector runs with lanes along x
 #pragma unroll

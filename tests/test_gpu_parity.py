@@ -841,9 +841,10 @@ def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
     the stop test can pass.  The plans choose WHICH sweeps are evaluated, never the arithmetic: conv_plan 1 (proven bound),
     2 (extrapolated), 3 (extrapolated, late stops repeated under 1) must return the sweep counts and fields of conv_plan 0
     (every sweep, as the reference: rayleigh.py:448-454) bit for bit, with no late stop; verify_conv (every sweep evaluated
-    next to the plan) must flag nothing under the proven plan; and with the test hook plan_overshoot = 12 plan 2 stops late
+    next to the plan) must flag nothing under the proven plan; the speculative opening of a solve (spec_start) must be inert in
+    the results whether it lands short or too far; and with the test hook plan_overshoot = 12 plan 2 stops late
     (counted) while plan 3 notices, repeats those solves and still returns the result of conv_plan 0."""
-    def run(plan, over=0, verify=0):
+    def run(plan, over=0, verify=0, spec=None):
         if kind == "rayleigh":
             env = V.VecRayleigh(6, DEV, dtype, None, L=1.0, H=3.0)
             rng = np.random.default_rng(5)
@@ -863,6 +864,8 @@ def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
         env.set_option("conv_plan", plan)
         env.set_option("plan_overshoot", over)
         env.set_option("verify_conv", verify)
+        if spec is not None:
+            env.set_option("spec_start", spec)
         env.step(a)
         assert env.kernel_name == "ns2d_fast4_step"
         torch.cuda.synchronize()
@@ -879,7 +882,15 @@ def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
         assert int(got[2][:, 2].sum()) == 0, plan                                        # no late stop
     ver = run(1, verify=1)
     assert torch.equal(ver[0], literal[0]) and not np.any(ver[3] & 4)
-    plan2, plan3 = run(2, over=12), run(3, over=12)
+    # the speculative opening of a solve (spec_start / 8 of the previous timestep's count as plain sweeps before the first
+    # evaluation; the rayleigh float32 default is 7): none, the default's neighbour, and 16 -- twice the previous count, which
+    # overshoots in every timestep and runs the repeat path -- under the extrapolating plans: never another result
+    for spec in (0, 6, 16):
+        for plan in (2, 3):
+            got = run(plan, spec=spec)
+            assert torch.equal(got[0], literal[0]) and torch.equal(got[1], literal[1]), (plan, spec)
+            assert int(got[2][:, 2].sum()) == 0, (plan, spec)
+    plan2, plan3 = run(2, over=12, spec=0), run(3, over=12, spec=0)
     assert int(plan2[2][:, 2].sum()) > 0 and int((plan2[0] > literal[0]).sum()) > 0     # the hook does provoke late stops
     assert int(plan3[2][:, 2].sum()) > 0 and int(plan3[2][:, 3].sum()) == int(plan3[2][:, 2].sum())
     assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
