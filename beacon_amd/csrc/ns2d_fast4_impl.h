@@ -466,40 +466,130 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
     __syncthreads();
     BCN_F4_PH(0)
 
+#ifndef BCN_F4_FUSE_RHS   // 1: predictor and Poisson rhs in ONE pass over the fields (below); 0: two passes (the rhs re-reads u*, v*)
+#define BCN_F4_FUSE_RHS 1
+#endif
+    auto pred_load = [&](int j, int i) {
+      const int c = j * SX + i;
+      F4Pred<real> q;
+      q.u[0] = u[c]; q.u[1] = u[c + 1]; q.u[2] = u[c - 1]; q.u[3] = u[c + SX]; q.u[4] = u[c - SX]; q.u[5] = u[c + 1 - SX];
+      q.v[0] = v[c]; q.v[1] = v[c + 1]; q.v[2] = v[c - 1]; q.v[3] = v[c + SX]; q.v[4] = v[c - SX]; q.v[5] = v[c + SX - 1];
+      q.p[0] = p[c]; q.p[1] = p[c - 1]; q.p[2] = p[c - SX];
+      q.s = (KIND == 0) ? S[c] : real(0);
+      return q;
+    };
+    // u* (cells with i >= 2) and v* (j >= 2) of one cell; 0 where the predictor computes nothing (walls, outside the grid)
+    auto pred_cell = [&](const F4Pred<real>& q, int j, int i, bool ok, real& us_o, real& vs_o) {
+      const real uc = q.u[0], uE_ = q.u[1], uW_ = q.u[2], uN_ = q.u[3], uS_ = q.u[4];
+      const real vc = q.v[0], vE_ = q.v[1], vW_ = q.v[2], vN_ = q.v[3], vS_ = q.v[4];
+      const real pc = q.p[0];
+      us_o = 0; vs_o = 0;
+      if (ok && i >= 2) {
+        real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
+        real uN = real(0.5) * (uN_ + uc), uS = real(0.5) * (uc + uS_);
+        real vN = real(0.5) * (vN_ + q.v[5]), vS = real(0.5) * (vc + vW_);
+        real conv = (uE * uE - uW * uW) * A.rdx + (uN * vN - uS * vS) * A.rdy;
+        real diff = ((uE_ - 2 * uc + uW_) * A.rdx2 + (uN_ - 2 * uc + uS_) * A.rdy2) * A.kmom;
+        real pres = (pc - q.p[1]) * A.rdx;
+        us_o = uc + A.dt * (diff - conv - pres);
+      }
+      if (ok && j >= 2) {
+        real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
+        real uE = real(0.5) * (uE_ + q.u[5]), uW = real(0.5) * (uc + uS_);
+        real vN = real(0.5) * (vN_ + vc), vS = real(0.5) * (vc + vS_);
+        real conv = (uE * vE - uW * vW) * A.rdx + (vN * vN - vS * vS) * A.rdy;
+        real diff = ((vE_ - 2 * vc + vW_) * A.rdx2 + (vN_ - 2 * vc + vS_) * A.rdy2) * A.kmom;
+        real pres = (pc - q.p[2]) * A.rdy;
+        vs_o = vc + A.dt * (diff - conv - pres + q.s);
+      }
+    };
+    if constexpr (BCN_F4_FUSE_RHS && CPL <= 2) {
+      // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) AND Poisson rhs (rayleigh.py:424-426) in one pass ----
+      // The rhs of a cell needs u* of its east neighbour and v* of its north neighbour.  With lanes along x the east value is
+      // the next lane's (one DPP move; the last lane's is the first lane's second column) -- and with the rows dealt to the
+      // waves in CONTIGUOUS chunks instead of round-robin, the north value is what the wave computes in its next iteration:
+      // the rhs of row j - 1 follows the predictor of row j, from registers.  A chunk's last row needs v* of the next
+      // chunk's first row: every wave leaves that row of v* in LDS (the exchange buffer is idle here) and the chunks' last
+      // rows get their rhs behind a barrier.  u*, v* still go to HBM for the corrector;
+      // what goes away is the pass that read them back (2 of the 17 passes over the fields) and its load latency.
+      // u*(1, j) = u*(nx + 1, j) = 0 and v*(i, 1) = v*(i, ny + 1) = 0 (walls: the predictor computes nothing there and
+      // the arrays hold the zeros they were created with -- what the two-pass form reads).
+      constexpr int RB = (NY + NW - 1) / NW;
+      static_assert(NW * P <= G::HAL, "one row of v* per wave in the exchange buffer");
+      const int ja = 1 + w * RB;
+      const int jz = (ja + RB - 1 < NY) ? ja + RB - 1 : NY;      // (ja > NY: no rows)
+      real usP[CPL], vsP[CPL];   // u*, v* of the last row done
+#pragma unroll
+      for (int a = 0; a < CPL; a++) { usP[a] = 0; vsP[a] = 0; }
+      // two rows per iteration (the loads of both -- four cells per lane at 100 columns -- go out before the arithmetic);
+      // branch-free like f4_cells: a row past the chunk is loaded from a clamped index and computed for nothing
+      for (int j = ja; j <= jz; j += 2) {
+        F4Pred<real> q[2][CPL];
+        real usC[2][CPL], vsC[2][CPL];
+        const bool two = j + 1 <= jz;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int a = 0; a < CPL; a++) {
+            const int jr = j + r, i = 1 + tx + BCN_WAVE * a;
+            q[r][a] = pred_load(jr <= jz ? jr : jz, i <= NX ? i : NX);
+          }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int a = 0; a < CPL; a++) {
+            const int jr = j + r, i = 1 + tx + BCN_WAVE * a;
+            const int jc = jr <= jz ? jr : jz;
+            const bool ok = (i <= NX) && (jr <= jz);
+            pred_cell(q[r][a], jc, i <= NX ? i : NX, ok, usC[r][a], vsC[r][a]);
+            const int c = jc * SX + (i <= NX ? i : NX);
+            if (ok && i >= 2) us[c] = usC[r][a];      // u*, v* to HBM for the corrector
+            if (ok && jr >= 2) vs[c] = vsC[r][a];
+            if (r == 0 && j == ja && i <= NX) hal[w * P + i] = vsC[0][a];   // the chunk's first row of v*, for the wave below
+          }
+        // rhs of rows j - 1 (u*, v* carried) and j
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int jr = j - 1 + r;                                   // the row whose rhs is complete now
+          const bool have = (r == 0) ? (j > ja) : two;
+#pragma unroll
+          for (int a = 0; a < CPL; a++) {
+            const int i = 1 + tx + BCN_WAVE * a;
+            const real u0 = (r == 0) ? usP[a] : usC[0][a], v0 = (r == 0) ? vsP[a] : vsC[0][a];
+            const real v1 = (r == 0) ? vsC[0][a] : vsC[1][a];
+            const real un = (r == 0) ? usP[a + 1 < CPL ? a + 1 : a] : usC[0][a + 1 < CPL ? a + 1 : a];
+            real usE = dpp<0x130, 0xf, 0xf, true>(real(0), u0);                        // the next lane's column
+            if (a + 1 < CPL) usE = (tx == BCN_WAVE - 1) ? read_lane(un, 0) : usE;     // (lane 63: the first lane's next column)
+            if (have && i <= NX) W[jr * P + i] = -(A.cb * ((usE - u0) * A.rdx + (v1 - v0) * A.rdy));
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < CPL; a++) { usP[a] = two ? usC[1][a] : usC[0][a]; vsP[a] = two ? vsC[1][a] : vsC[0][a]; }
+      }
+      __syncthreads();
+      // the chunk's last row: v* of the row above it is the next wave's first row (the top wall's 0 for the last chunk)
+      if (ja <= NY) {
+#pragma unroll
+        for (int a = 0; a < CPL; a++) {
+          const int i = 1 + tx + BCN_WAVE * a;
+          const real v1 = (jz < NY && i <= NX) ? hal[(w + 1) * P + (i <= NX ? i : NX)] : real(0);
+          const real un = usP[a + 1 < CPL ? a + 1 : a];
+          real usE = dpp<0x130, 0xf, 0xf, true>(real(0), usP[a]);
+          if (a + 1 < CPL) usE = (tx == BCN_WAVE - 1) ? read_lane(un, 0) : usE;
+          if (i <= NX) W[jz * P + i] = -(A.cb * ((usE - usP[a]) * A.rdx + (v1 - vsP[a]) * A.rdy));
+        }
+      }
+      __syncthreads();
+      BCN_F4_PH(1)
+    } else {
     // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) ----
-    f4_cells<NX, NW, UP>(w, tx, 1, NY,
-      [&](int j, int i) {
-        const int c = j * SX + i;
-        F4Pred<real> q;
-        q.u[0] = u[c]; q.u[1] = u[c + 1]; q.u[2] = u[c - 1]; q.u[3] = u[c + SX]; q.u[4] = u[c - SX]; q.u[5] = u[c + 1 - SX];
-        q.v[0] = v[c]; q.v[1] = v[c + 1]; q.v[2] = v[c - 1]; q.v[3] = v[c + SX]; q.v[4] = v[c - SX]; q.v[5] = v[c + SX - 1];
-        q.p[0] = p[c]; q.p[1] = p[c - 1]; q.p[2] = p[c - SX];
-        q.s = (KIND == 0) ? S[c] : real(0);
-        return q;
-      },
+    f4_cells<NX, NW, UP>(w, tx, 1, NY, pred_load,
       [&](const F4Pred<real>& q, int j, int i, bool ok) {
         const int c = j * SX + i;
-        const real uc = q.u[0], uE_ = q.u[1], uW_ = q.u[2], uN_ = q.u[3], uS_ = q.u[4];
-        const real vc = q.v[0], vE_ = q.v[1], vW_ = q.v[2], vN_ = q.v[3], vS_ = q.v[4];
-        const real pc = q.p[0];
-        if (ok && i >= 2) {
-          real uE = real(0.5) * (uE_ + uc), uW = real(0.5) * (uc + uW_);
-          real uN = real(0.5) * (uN_ + uc), uS = real(0.5) * (uc + uS_);
-          real vN = real(0.5) * (vN_ + q.v[5]), vS = real(0.5) * (vc + vW_);
-          real conv = (uE * uE - uW * uW) * A.rdx + (uN * vN - uS * vS) * A.rdy;
-          real diff = ((uE_ - 2 * uc + uW_) * A.rdx2 + (uN_ - 2 * uc + uS_) * A.rdy2) * A.kmom;
-          real pres = (pc - q.p[1]) * A.rdx;
-          us[c] = uc + A.dt * (diff - conv - pres);
-        }
-        if (ok && j >= 2) {
-          real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
-          real uE = real(0.5) * (uE_ + q.u[5]), uW = real(0.5) * (uc + uS_);
-          real vN = real(0.5) * (vN_ + vc), vS = real(0.5) * (vc + vS_);
-          real conv = (uE * vE - uW * vW) * A.rdx + (vN * vN - vS * vS) * A.rdy;
-          real diff = ((vE_ - 2 * vc + vW_) * A.rdx2 + (vN_ - 2 * vc + vS_) * A.rdy2) * A.kmom;
-          real pres = (pc - q.p[2]) * A.rdy;
-          vs[c] = vc + A.dt * (diff - conv - pres + q.s);
-        }
+        real us_o, vs_o;
+        pred_cell(q, j, i, ok, us_o, vs_o);
+        if (ok && i >= 2) us[c] = us_o;
+        if (ok && j >= 2) vs[c] = vs_o;
       });
     __syncthreads();
     BCN_F4_PH(1)
@@ -514,6 +604,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         if (ok) W[j * P + i] = -(A.cb * ((q.u1 - q.u0) * A.rdx + (q.v1 - q.v0) * A.rdy));
       });
     __syncthreads();
+    }
 
     // ---- Jacobi sweeps in registers (rayleigh.py:419-454 / mixing.py:428-463) ----
     const unsigned long long tj0 = __builtin_amdgcn_s_memtime();
