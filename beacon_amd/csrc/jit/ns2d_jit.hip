@@ -24,7 +24,12 @@
 extern "C" {
 
 __attribute__((visibility("default"))) int bcn_jit_launch(const void* args, int batch, void* stream) {
+#ifdef BCN_JIT_BREAK   // TEST HOOK (tests/test_gpu_parity.py): a deliberately wrong kernel -- the first-use self-check of beacon_amd/jit.py must refuse it
+  NS2DArgs<BCN_JIT_REAL> a = *static_cast<const NS2DArgs<BCN_JIT_REAL>*>(args);
+  a.dt *= BCN_JIT_REAL(1.5);
+#else
   const NS2DArgs<BCN_JIT_REAL>& a = *static_cast<const NS2DArgs<BCN_JIT_REAL>*>(args);
+#endif
   if (a.nx != BCN_JIT_NX || a.ny != BCN_JIT_NY || a.kind != BCN_JIT_KIND) {
     bcn_set_error("kernel plugin built for %dx%d kind %d, handle is %dx%d kind %d", BCN_JIT_NX, BCN_JIT_NY, BCN_JIT_KIND,
                   a.nx, a.ny, a.kind);

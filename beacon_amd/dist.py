@@ -147,9 +147,24 @@ class ShardedVecEnv(object):
     stream; `seed` defaults to the seed the env itself was constructed with (VecBurgers(seed=...)), and an
     unsharded env (world size 1) keeps its generator untouched."""
 
-    NBUF = int(os.environ.get("BEACON_NBUF", "3"))      # output buffers of the overlapped path (>= 2)
+    NBUF = 3      # default number of output buffers of the overlapped path (constructor argument `nbuf`, >= 2)
 
-    def __init__(self, local_env, group=None, seed=None, always_collective=False, overlap=False):
+    def __init__(self, local_env, group=None, seed=None, always_collective=False, overlap=False, nbuf=None, check_calls=None):
+        """nbuf: output buffers of the overlapped path (default: environment BEACON_NBUF, else 3; at least 2 -- step k + nbuf
+        overwrites what gather k reads).  check_calls (default: environment BEACON_DIST_CHECK=1): every reset() / step()
+        first verifies, with one tiny all-reduce and a host read, that all ranks made the same call with the same
+        mask / no-mask shape -- a debugging aid for SPMD trainer scripts (it serialises host and device; leave it off when
+        timing)."""
+        if nbuf is None:
+            raw = os.environ.get("BEACON_NBUF", str(ShardedVecEnv.NBUF))
+            try:
+                nbuf = int(raw)
+            except ValueError:
+                raise ValueError("BEACON_NBUF=%r is not an integer" % raw)
+        if int(nbuf) < 2:
+            raise ValueError("ShardedVecEnv: nbuf = %s, need at least 2 output buffers" % nbuf)
+        self.NBUF = int(nbuf)
+        self.check_calls = (os.environ.get("BEACON_DIST_CHECK") == "1") if check_calls is None else bool(check_calls)
         self.env = local_env
         self.sh = ReplicaSharder(local_env.batch, group, always_collective)
         self.global_batch = self.sh.global_batch
@@ -177,10 +192,25 @@ class ShardedVecEnv(object):
         shape = (e.batch,) if e.n_actions == 1 else (e.batch, e.n_actions)
         return torch.empty(shape, dtype=e.tdtype, device=e.device)
 
+    def _check_call(self, what, has_mask, scattered):
+        """check_calls: all ranks are in the same call with the same shape (which collectives follow depends on it: a rank that
+        passes mask=None while rank 0 passes a mask would skip the mask scatter and meet rank 0 in the wrong collective)."""
+        if not (self.check_calls and self.sh.collective):
+            return
+        code = float(1 + 4 * ("reset", "step", "reset_done").index(what) + (1 if has_mask else 0) + (2 if scattered else 0))
+        t = torch.tensor([code, -code], dtype=torch.float32, device=self.env.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.sh.group)
+        hi, lo = float(t[0]), -float(t[1])
+        if hi != lo:
+            raise RuntimeError("ShardedVecEnv.%s: the ranks disagree on the call (rank %d: %s, mask %s, scattered %s; codes %g..%g): "
+                               "every rank must make the same call, with a non-None `mask` placeholder wherever rank 0 passes a mask"
+                               % (what, self.sh.rank, what, "given" if has_mask else "None", scattered, lo, hi))
+
     def _local_mask(self, mask_global, scattered):
         """mask_global: [B_global] bool / uint8 on rank 0, or every rank's own [B_local] slice when `scattered`; None = all
         replicas.  As with torch.distributed's own scatter, the CALL is collective and only the payload is rank 0's:
-        when rank 0 passes a mask, every other rank passes a non-None placeholder (its content is ignored)."""
+        when rank 0 passes a mask, every other rank passes a non-None placeholder (its content is ignored) -- the ranks of
+        an SPMD trainer script make the same calls, and `check_calls` verifies it."""
         if mask_global is None or scattered or not self.sh.collective:
             return mask_global
         like = torch.empty((self.env.batch,), dtype=torch.uint8, device=self.env.device)
@@ -242,6 +272,7 @@ class ShardedVecEnv(object):
         scattered=True): what the reference's trainer does when it calls reset() on the one env whose episode ended
         (rayleigh.py:89-99).  Returns the global observations on rank 0."""
         self._drain()
+        self._check_call("reset", mask is not None, scattered)
         m = self._local_mask(mask, scattered)
         self.env.reset(mask=m)
         g = self._gather()
@@ -251,6 +282,7 @@ class ShardedVecEnv(object):
         """Auto-reset on every rank of its own replicas whose last step() returned done (VecEnv.reset_done: on the device,
         no mask travels), then the gather of the refreshed observations."""
         self._drain()
+        self._check_call("reset_done", False, False)
         self.env.reset_done()
         g = self._gather()
         return (g[0] if g is not None else None), None
@@ -261,6 +293,7 @@ class ShardedVecEnv(object):
         slice.  With overlap=False the gather is a blocking collective on the caller's stream and the PendingStep is
         already complete."""
         e = self.env
+        self._check_call("step", mask is not None, scattered)
         if scattered or not self.sh.collective:
             local = actions_global
         else:

@@ -8,7 +8,16 @@ reference's defaults; for any other grid `plugin_for()` compiles csrc/jit/ns2d_j
 (about 30 s, once: the shared object is cached in beacon_amd/_jit/, keyed by a hash of its sources and flags, and
 travels with the tree like the library itself) and hands its launcher to the library through bcn_set_fast_plugin.
 No hipcc, BEACON_JIT=0 or a grid the mapping cannot hold (ny > 256, LDS, registers) -> None: the env keeps the
-generic kernel (still on the GPU; only slower)."""
+generic kernel (still on the GPU; only slower).
+
+First-use self-check.  A plugin is a NEW template instantiation compiled on the user's box, at the register limit of the
+target (256 VGPRs plus spills), and round 4 met one such instantiation that computed wrong results under a neutral source
+change (the 110x64 float64 two-body kernel).  So no plugin is attached on trust: the first env that wants it runs
+`verify()` -- six timesteps of a seeded state through the plugin (plain launch and ticket scheduler) and through the generic
+kernel, which is ordinary HIP without hand-scheduled code: float64 fields within 1e-9 with equal sweep counts (+-1), float32
+within the on-demand grids' tolerance.  Agreement is remembered next to the shared object (`<plugin>.ok`, tagged with the device
+and the HIP runtime, so another box checks again); a mismatch leaves `<plugin>.bad`, warns, and the env -- this one and every
+later one -- keeps the generic kernel."""
 import ctypes as C
 import fcntl
 import hashlib
@@ -107,6 +116,105 @@ def choose(nx, ny, f64, kind):
     return _choose4(nx, ny, f64)
 
 
+CHECKING = False      # inside verify(): the envs it builds attach the plugin without verifying it again
+
+
+def _runtime_tag():
+    import torch
+    try:
+        name = torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName
+    except Exception:      # noqa: BLE001
+        name = "?"
+    return "%s hip %s" % (name, getattr(torch.version, "hip", None))
+
+
+def _seeded_rayleigh_state(env):
+    import numpy as np
+    x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+    st0 = np.zeros((4, env.nx + 2, env.ny + 2))
+    st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x * env.L)[:, None] * np.sin(np.pi * y)[None, :]
+    return np.tile(np.ascontiguousarray(st0.transpose(0, 2, 1))[None], (env.batch, 1, 1, 1))
+
+
+def compare_with_generic(make_env, kind, f64, ndt=6, batch=3):
+    """(ok, report): `ndt` timesteps of a seeded state through the attached register-resident kernel -- plain launch and
+    ticket scheduler (chunks of two timesteps on two persistent workgroups: hand-offs through HBM) -- against the generic
+    kernel.  float64: fields within 1e-9 (p 5e-8), sweep counts within 1; float32: 2e-4 (p 1e-2), counts within max(3, 2 %)."""
+    import numpy as np
+    import torch
+    runs = {}
+    for tag, variant, sched in (("generic", 0, None), ("plain", 1, (0, 0, 0)), ("ticket", 1, (2, 2, 2))):
+        env = make_env(batch)
+        try:
+            env.set_ndt_act(ndt)
+            got = env.set_variant(variant)
+            if sched is not None:
+                env.set_sched(*sched)
+            env.reset()
+            if kind == 0:
+                env.set_state(_seeded_rayleigh_state(env))
+                a = np.random.default_rng(3).uniform(-1, 1, (batch, env.n_sgts))
+            else:
+                a = np.array([0, 2, 3] * batch)[:batch]
+            env.step(a)
+            torch.cuda.synchronize(env.device)
+            runs[tag] = (env.get_state().double().cpu().numpy(), env.sweeps.cpu().numpy().astype(np.int64),
+                         env.status.cpu().numpy().copy(), env.kernel_name, got)
+        finally:
+            env.close()
+    ref = runs["generic"]
+    tol = 1e-9 if f64 else 2e-4
+    rep, ok = [], True
+    for tag in ("plain", "ticket"):
+        st, sw, status, kname, got = runs[tag]
+        d = np.abs(st - ref[0])
+        d = np.where(np.isfinite(d), d, np.inf)
+        dp, dr = float(d[:, 2].max()), float(np.delete(d, 2, axis=1).max())
+        ds = int(np.abs(sw - ref[1]).max())
+        good = (got == 1 and not status.any() and not ref[2].any() and dr <= tol and dp <= 50 * tol and
+                ds <= (1 if f64 else max(3, int(0.02 * ref[1].max()))))
+        ok = ok and good
+        rep.append("%s (%s): fields %.2e p %.2e sweeps %d of %d status %s%s" % (tag, kname, dr, dp, ds, int(ref[1].max()),
+                                                                                 np.unique(status).tolist(), "" if good else "  <-- MISMATCH"))
+    return ok, "; ".join(rep)
+
+
+def verify(p, make_env, kind, f64):
+    """Sets p.verified (True / False) -- from the marker files next to the shared object, or by running compare_with_generic()."""
+    global CHECKING
+    okf, badf = p.path + ".ok", p.path + ".bad"
+    if os.path.exists(badf):
+        p.verified = False
+        warnings.warn("beacon_amd.jit: %s failed its self-check earlier (%s); the generic kernel stays selected"
+                      % (os.path.basename(p.path), open(badf).read().strip()[:300]))
+        return
+    tag = _runtime_tag()
+    try:
+        if os.path.exists(okf) and open(okf).read().split("\n")[0].strip() == tag:
+            p.verified = True
+            return
+    except OSError:
+        pass
+    CHECKING = True
+    try:
+        ok, rep = compare_with_generic(make_env, kind, f64)
+    except Exception as e:      # noqa: BLE001 -- could not run (out of memory, ...): no verdict, no plugin for this env
+        warnings.warn("beacon_amd.jit: the self-check of %s could not run (%s: %s); the generic kernel stays selected for this env"
+                      % (os.path.basename(p.path), type(e).__name__, e))
+        return
+    finally:
+        CHECKING = False
+    p.verified, p.report = bool(ok), rep
+    try:
+        with open(okf if ok else badf, "w") as fh:
+            fh.write("%s\n%s\n" % (tag, rep))
+    except OSError:
+        pass                    # read-only package directory: the verdict holds for this process
+    if not ok:
+        warnings.warn("beacon_amd.jit: the register-resident kernel %s DISAGREES with the generic kernel on its self-check (%s); "
+                      "it is not used: the generic kernel stays selected" % (os.path.basename(p.path), rep))
+
+
 def _signature(defs):
     h = hashlib.sha256()
     h.update(repr((_build.ARCH, _build.FLAGS, _build.FILE_FLAGS.get("ns2d_fast.hip"), sorted(defs.items()))).encode())
@@ -118,8 +226,9 @@ def _signature(defs):
     return h.hexdigest()[:12]
 
 
-def build_plugin(nx, ny, f64, kind, verbose=False):
-    """Path of the shared object for this grid (compiling it if needed), or None."""
+def build_plugin(nx, ny, f64, kind, verbose=False, extra_defs=None):
+    """Path of the shared object for this grid (compiling it if needed), or None.  extra_defs: more -D flags (part of the
+    plugin's name hash), e.g. {"BCN_JIT_BREAK": 1} -- the deliberately wrong kernel of the self-check's own test."""
     m = choose(nx, ny, f64, kind)
     if m is None or os.environ.get("BEACON_JIT", "1") == "0":
         return None
@@ -131,6 +240,7 @@ def build_plugin(nx, ny, f64, kind, verbose=False):
         defs["BCN_JIT_WPE"] = int(os.environ["BEACON_JIT_WPE"])
     for d in os.environ.get("BEACON_JIT_DEFS", "").split():   # experiments: extra -D flags (scripts/tall_base.py)
         defs[d.partition("=")[0]] = d.partition("=")[2] or "1"
+    defs.update(extra_defs or {})
     name = "ns2d_%dx%d_%s_k%d_r%d_%s.so" % (nx, ny, "f64" if f64 else "f32", kind, m["R"], _signature(defs))
     path = os.path.join(JIT_DIR, name)
     if os.path.exists(path):
@@ -176,13 +286,15 @@ class Plugin(object):
         self.fn = C.cast(self.lib.bcn_jit_launch, C.c_void_p)
         self.scratch = int(self.lib.bcn_jit_scratch_elems())
         self.lds = int(self.lib.bcn_jit_lds_bytes())
+        self.verified = None          # True / False once verify() has compared it with the generic kernel
+        self.report = ""
 
 
-def plugin_for(nx, ny, f64, kind):
+def plugin_for(nx, ny, f64, kind, extra_defs=None):
     """Loaded plugin (kept alive for the life of the process) for this grid, or None."""
-    key = (nx, ny, bool(f64), kind)
+    key = (nx, ny, bool(f64), kind, tuple(sorted((extra_defs or {}).items())))
     if key not in _LOADED:
-        path = build_plugin(nx, ny, f64, kind)
+        path = build_plugin(nx, ny, f64, kind, extra_defs=extra_defs)
         try:
             p = Plugin(path) if path else None
         except (OSError, AttributeError) as e:        # a truncated or foreign shared object in the cache
@@ -203,12 +315,50 @@ TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 6
               (300, 50, False, 0), (200, 100, False, 1), (53, 150, False, 0), (106, 200, False, 1)]
 
 
+def fuzz_grids(seed=5):
+    """22 random domain sizes with a register-resident mapping, as (L, H, f64, kind): the reference takes any L, H
+    (rayleigh.py:20-27, mixing.py:20-28).  Drawn until every kernel family has its quota -- (rows per lane, float64):
+    one row 4 + 3, two rows 4 + 3, the hybrid 6 + 2.  Seeded, so that __graft_entry__.build() compiles exactly the plugins
+    that tests/test_gpu_parity.py::test_jit_fuzzed_grids_agree_with_the_generic_kernel asks for."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    quota = {(1, False): 4, (1, True): 3, (2, False): 4, (2, True): 3, (4, False): 6, (4, True): 2}
+    out = []
+    while any(quota.values()):
+        kind = int(rng.integers(0, 2))
+        f64 = bool(rng.integers(0, 2))
+        if kind == 0:        # (below L, H = 1 the reference divides by zero: nx_obs_pts = 4 int(L))
+            L = round(float(rng.uniform(1.0, 4.5)), 2)
+            H = round(float(rng.uniform(1.0, 1.3) if rng.integers(0, 2) else rng.uniform(1.0, 3.2)), 2)
+            nx, ny = int(50 * L), int(50 * H)
+        else:
+            L, H = round(float(rng.uniform(1.0, 1.7)), 2), round(float(rng.uniform(1.0, 2.3)), 2)
+            nx, ny = int(100 * L), int(100 * H)
+        m = choose(nx, ny, f64, kind)
+        if m is None or nx * ny > 30000 or not quota.get((m["rows"], f64)):
+            continue
+        quota[(m["rows"], f64)] -= 1
+        out.append((L, H, f64, kind))
+    return out
+
+
+def fuzz_grid_keys():
+    return [((int(50 * L), int(50 * H)) if kind == 0 else (int(100 * L), int(100 * H))) + (f64, kind) for L, H, f64, kind in fuzz_grids()]
+
+
+# plugins built with extra -D flags: the deliberately wrong kernel of the self-check's own test
+EXTRA_BUILDS = [((75, 50, True, 0), {"BCN_JIT_BREAK": 1})]
+
+
 def prebuild(grids=None, verbose=False):
     """Compile the plugins of a list of (nx, ny, f64, kind) grids (used by __graft_entry__.build() for the grids the
     tests touch, so that they ship with the tree)."""
     from concurrent.futures import ThreadPoolExecutor
+    todo = [(g, None) for g in (grids or (TEST_GRIDS + [k for k in fuzz_grid_keys() if k not in TEST_GRIDS]))]
+    if grids is None:
+        todo += EXTRA_BUILDS
     with ThreadPoolExecutor(max_workers=int(os.environ.get("BEACON_JIT_JOBS", "4"))) as ex:
-        paths = list(ex.map(lambda g: build_plugin(g[0], g[1], g[2], g[3], verbose), grids or TEST_GRIDS))
+        paths = list(ex.map(lambda t: build_plugin(t[0][0], t[0][1], t[0][2], t[0][3], verbose, t[1]), todo))
     if os.path.isdir(JIT_DIR):
         # drop the plugins of older source states of THESE grids (same name up to the hash); plugins that users compiled
         # on demand for other grids stay (a stale one is merely unused: build_plugin() compiles the current hash next to it)
@@ -217,6 +367,9 @@ def prebuild(grids=None, verbose=False):
         for f in os.listdir(JIT_DIR):
             if f.endswith(".so") and f not in keep and f.rsplit("_", 1)[0] in stems:
                 os.remove(os.path.join(JIT_DIR, f))
+                for mark in (".ok", ".bad"):
+                    if os.path.exists(os.path.join(JIT_DIR, f + mark)):
+                        os.remove(os.path.join(JIT_DIR, f + mark))
             elif f.endswith(".lock"):
                 # a lock file another process holds (flock) must stay: unlinking it would let a third process lock a NEW
                 # file of the same name and compile the same plugin beside the holder

@@ -55,6 +55,7 @@ class VecEnv(object):
 
     action_is_int = False
     needs_noise = False
+    _plugin_defs = None      # extra -D flags of this class's on-demand kernels (tests: the deliberately broken plugin)
 
     def __init__(self, batch, device="cuda:0", dtype="f32"):
         if not torch.cuda.is_available():
@@ -181,8 +182,15 @@ class VecEnv(object):
         if self.lib.bcn_set_variant(self.h, 1) == 1 and os.environ.get("BEACON_JIT_FORCE") != "1":
             return
         from . import jit
-        p = jit.plugin_for(self.nx, self.ny, self.tdtype == torch.float64, kind)
-        if p is not None:
+        f64 = self.tdtype == torch.float64
+        p = jit.plugin_for(self.nx, self.ny, f64, kind, getattr(self, "_plugin_defs", None))
+        if p is None:
+            return
+        if p.verified is None and not jit.CHECKING:
+            # first use of this shared object: compared with the generic kernel before any env runs on it (jit.verify)
+            ctor, cls, dev, dt = dict(self._ctor), type(self), self.device, ("f64" if f64 else "f32")
+            jit.verify(p, lambda batch: cls(batch, dev, dt, **ctor), kind, f64)
+        if p.verified or jit.CHECKING:
             _lib.check(self.lib.bcn_set_fast_plugin(self.h, p.fn, p.scratch))
             self._plugin = p
 
@@ -337,6 +345,7 @@ class VecRayleigh(VecEnv):
     def __init__(self, batch, device="cuda:0", dtype="f32", init_fields=None,
                  L=1.0, H=1.0, n_sgts=10, ra=1.0e4):
         self._derive(L, H, n_sgts, ra)
+        self._ctor = dict(L=L, H=H, n_sgts=n_sgts, ra=ra)     # a twin of this env (the JIT self-check builds some)
         self._init_np = None if init_fields is None else np.asarray(init_fields, dtype=np.float64)
         super().__init__(batch, device, dtype)
         self._post_init()
@@ -445,6 +454,7 @@ class VecMixing(VecEnv):
     def __init__(self, batch, device="cuda:0", dtype="f32", L=1.0, H=1.0, re=100.0, pe=10000.0,
                  side=0.5, C0=1.0):
         self._derive(L, H, re, pe, side, C0)
+        self._ctor = dict(L=L, H=H, re=re, pe=pe, side=side, C0=C0)
         super().__init__(batch, device, dtype)
         self._make_spaces()
         self.sweeps = torch.zeros((self.batch, self.ndt_act), dtype=torch.int32, device=self.device)

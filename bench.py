@@ -127,7 +127,7 @@ def launch_children(n, argv, poll_s=0.1, grace_s=5.0):
 # ------------------------------------------------------------------------------------------------
 # accounting
 # ------------------------------------------------------------------------------------------------
-def committed_profile(kernel_name, key, dtype="f32"):
+def committed_profile(kernel_name, key, dtype="f32", grid_tag=None):
     """Per-dispatch counters from the committed rocprofv3 PMC passes (profiles/*_summary.json, produced by
     scripts/prof.sh: separate --pmc passes; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 as the MI355X guide
     prescribes for gfx950).  Latest file wins; None if absent."""
@@ -140,6 +140,8 @@ def committed_profile(kernel_name, key, dtype="f32"):
             continue
         for name, c in d.get("pmc", {}).items():
             real = "<double" if dtype == "f64" else "<float"
+            if grid_tag and "<" in name and grid_tag not in name:
+                continue                         # another grid's instantiation of the same kernel template
             if name.startswith(kernel_name) and (real in name or "<" not in name) and key in c and "reset" not in name:
                 best = {"value": c[key], "source": os.path.basename(f), "sweeps_per_dispatch": c.get("sweeps_per_dispatch")}
     return best
@@ -338,89 +340,140 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
               "late_stops_last_step": int(c[:, 2].sum()), "repeated_timesteps_last_step": int(c[:, 3].sum())})
         env.close()
 
-    # what the float32 stop rule's shortcuts buy: the proven plan, the unguarded extrapolation,
-    # no speculative jump -- on the headline workload
-    headline_variant("headline workload, float32, conv_plan=1 (proven stop sweep)", "f32", {"conv_plan": 1},
-                     "residual evaluated on every sweep a proven lower bound of the norm cannot exclude; jump proven too")
-    headline_variant("headline workload, float32, conv_plan=1, spec_start=0", "f32", {"conv_plan": 1, "spec_start": 0},
-                     "proven plan without the speculative jump")
-    headline_variant("headline workload, float32, spec_start=0", "f32", {"spec_start": 0},
-                     "default plan (3: extrapolated, late stops repeated under plan 1) without the speculative jump")
-    headline_variant("headline workload, float32, conv_plan=2 (unguarded)", "f32", {"conv_plan": 2},
-                     "extrapolating plan without the late-stop guard (round 2's default)")
-    # rayleigh 128x64 float64 (the reference's arithmetic), B=512, the headline's own steps
-    headline_variant("headline workload (rayleigh-v0 128x64 B=512) in float64", "f64", {}, "the reference's arithmetic; proven plan (conv_plan 1)")
-    headline_variant("headline workload in float64, conv_plan=3", "f64", {"conv_plan": 3},
-                     "the float32 default's stop rule (extrapolated, late stops repeated under the proven plan) in the reference's arithmetic")
-    # mixing 100x100 B=512 (configs[4])
-    env = V.VecMixing(512, dev, "f32")
-    env.reset()
     ai = torch.as_tensor(rng.integers(0, 4, (8, 512)), dtype=torch.int32, device=dev)
-    k = [0]
+    a1 = torch.as_tensor(rng.uniform(-1, 1, (1024,)), dtype=torch.float32, device=dev)
 
-    def st():
-        env.step(ai[k[0] % 8]); k[0] += 1
-    ms = timed(env, st, quick_steps, warm=2)
-    line("mixing-v0 100x100 B=512 float32 (configs[4])", env, ms,
-         algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 4),
-         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
-    env.close()
-    # mixing 100x100 B=512 float64 (the reference's arithmetic)
-    env = V.VecMixing(512, dev, "f64")
-    env.reset()
-    k = [0]
-    ms = timed(env, st, 2, warm=1)
-    line("mixing-v0 100x100 B=512 float64", env, ms, algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 8),
-         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
-    env.close()
-    # a grid above ny = 128 (the reference takes any L, H: mixing.py:20-28): mixing(L=1, H=2) = 100x200, B=256 -- ns2d_fast4
-    # (Poisson solve in registers, the other phases from HBM/L2; the generic kernel needs 574 ms for this step)
-    env = V.VecMixing(256, dev, "f32", L=1.0, H=2.0)
-    env.reset()
-    k = [0]
-    ai2 = ai[:, :256].contiguous()
+    def leg_stop_rules():
+        # what the float32 stop rule's shortcuts buy: the proven plan, the unguarded extrapolation,
+        # no speculative jump -- on the headline workload
+        headline_variant("headline workload, float32, conv_plan=1 (proven stop sweep)", "f32", {"conv_plan": 1},
+                         "residual evaluated on every sweep a proven lower bound of the norm cannot exclude; jump proven too")
+        headline_variant("headline workload, float32, conv_plan=1, spec_start=0", "f32", {"conv_plan": 1, "spec_start": 0},
+                         "proven plan without the speculative jump")
+        headline_variant("headline workload, float32, spec_start=0", "f32", {"spec_start": 0},
+                         "default plan (3: extrapolated, late stops repeated under plan 1) without the speculative jump")
+        headline_variant("headline workload, float32, conv_plan=2 (unguarded)", "f32", {"conv_plan": 2},
+                         "extrapolating plan without the late-stop guard (round 2's default)")
 
-    def st2():
-        env.step(ai2[k[0] % 8]); k[0] += 1
-    ms = timed(env, st2, 2, warm=2)
-    line("mixing-v0 L=1 H=2 (100x200) B=256 float32", env, ms, algorithmic_bytes(100, 200, env.sweeps.cpu().numpy(), 4),
-         {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
-    env.close()
-    # burgers N=512 B=1024 (configs[1]): 12 B per cell per timestep
-    env = V.VecBurgers(1024, dev, "f32", nx=512)
-    env.reset()
-    a1 = torch.as_tensor(rng.uniform(-1, 1, (1024,)), dtype=env.tdtype, device=dev)
-    ms = timed_loop(env, lambda: env.step(a1), 200)
-    line("burgers-v0 N=512 B=1024 float32 (configs[1])", env, ms, 12.0 * 512 * env.ndt_act * 1024,
-         {"ms_per_step_in_hip_graph": timed_graph(env, a1), "inlet_noise": "drawn inside the step kernel (bcn_set_noise)"})
-    env.close()
-    # shkadov N=4096 10 jets B=1024 (configs[2]): 32 B per cell per timestep
-    env = V.VecShkadov(1024, dev, "f32", None, L0=699.2, n_jets=10)
-    env.reset()
-    # from a DEVELOPED film (shkadov/init.py:13-27: 4000 uncontrolled action steps under inlet noise), not the flat one:
-    # the limiter branches and the noise amplification are what a trainer's steps run through
-    env.warmup(env.n_warmup_ref, torch.zeros((1024, 10), dtype=env.tdtype, device=dev))
-    amp = float((env.get_state()[:, 0] - 1.0).abs().amax(dim=1).mean())
-    a10 = torch.as_tensor(rng.uniform(-1, 1, (64, 1024, 10)), dtype=env.tdtype, device=dev)
-    k = [0]
+    def leg_headline_f64():
+        # rayleigh 128x64 float64 (the reference's arithmetic), B=512, the headline's own steps
+        headline_variant("headline workload (rayleigh-v0 128x64 B=512) in float64", "f64", {}, "the reference's arithmetic; proven plan (conv_plan 1)")
+        headline_variant("headline workload in float64, conv_plan=3", "f64", {"conv_plan": 3},
+                         "the float32 default's stop rule (extrapolated, late stops repeated under the proven plan) in the reference's arithmetic")
 
-    def st_shk():
-        env.step(a10[k[0] % 64]); k[0] += 1
-    ms = timed_loop(env, st_shk, 50)
-    line("shkadov-v0 N=4096 10 jets B=1024 float32 (configs[2])", env, ms, 32.0 * env.nx * env.ndt_act * 1024,
-         {"ms_per_step_in_hip_graph": timed_graph(env, a10[0]), "inlet_noise": "drawn inside the step kernel (bcn_set_noise)",
-          "initial_state": "developed on the device: %d uncontrolled action steps under inlet noise; mean wave amplitude max|h-1| = %.3f"
-                           % (env.n_warmup_ref, amp),
-          "actions": "uniform(-1, 1) per replica, jet and step", "blown_up_replicas_after_timing": int((env.status & 2).bool().sum())})
-    env.close()
-    # sloshing (reference default grid) B=1024: 32 B per cell per timestep
-    env = V.VecSloshing(1024, dev, "f32", packaged_init("sloshing"))
-    env.reset()
-    ms = timed_loop(env, lambda: env.step(a1), 200)
-    line("sloshing-v0 N=200 B=1024 float32", env, ms, 32.0 * (env.nx + 2) * env.ndt_act * 1024,
-         {"ms_per_step_in_hip_graph": timed_graph(env, a1)})
-    env.close()
+    def leg_mixing_f32():
+        # mixing 100x100 B=512 (configs[4])
+        env = V.VecMixing(512, dev, "f32")
+        env.reset()
+        k = [0]
+
+        def st():
+            env.step(ai[k[0] % 8]); k[0] += 1
+        ms = timed(env, st, max(quick_steps, 8), warm=2)
+        line("mixing-v0 100x100 B=512 float32 (configs[4])", env, ms,
+             algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 4),
+             {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+        env.close()
+
+    def leg_mixing_f64():
+        # mixing 100x100 B=512 float64 (the reference's arithmetic)
+        env = V.VecMixing(512, dev, "f64")
+        env.reset()
+        k = [0]
+
+        def st():
+            env.step(ai[k[0] % 8]); k[0] += 1
+        ms = timed(env, st, 5, warm=1)
+        line("mixing-v0 100x100 B=512 float64", env, ms, algorithmic_bytes(100, 100, env.sweeps.cpu().numpy(), 8),
+             {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+        env.close()
+
+    def leg_tall_grid():
+        # a grid above ny = 128 (the reference takes any L, H: mixing.py:20-28): mixing(L=1, H=2) = 100x200, B=256 -- ns2d_fast4
+        # (Poisson solve in registers, the other phases from HBM/L2; the generic kernel needs 574 ms for this step)
+        env = V.VecMixing(256, dev, "f32", L=1.0, H=2.0)
+        env.reset()
+        k = [0]
+        ai2 = ai[:, :256].contiguous()
+
+        def st2():
+            env.step(ai2[k[0] % 8]); k[0] += 1
+        ms = timed(env, st2, 5, warm=2)
+        line("mixing-v0 L=1 H=2 (100x200) B=256 float32", env, ms, algorithmic_bytes(100, 200, env.sweeps.cpu().numpy(), 4),
+             {"mean_jacobi_sweeps_per_timestep": float(env.sweeps.float().mean())})
+        env.close()
+
+    def leg_burgers():
+        # burgers N=512 B=1024 (configs[1]): 12 B per cell per timestep
+        env = V.VecBurgers(1024, dev, "f32", nx=512)
+        env.reset()
+        ms = timed_loop(env, lambda: env.step(a1), 200)
+        line("burgers-v0 N=512 B=1024 float32 (configs[1])", env, ms, 12.0 * 512 * env.ndt_act * 1024,
+             {"ms_per_step_in_hip_graph": timed_graph(env, a1), "inlet_noise": "drawn inside the step kernel (bcn_set_noise)"})
+        env.close()
+
+    def leg_shkadov():
+        # shkadov N=4096 10 jets B=1024 (configs[2]): 32 B per cell per timestep
+        env = V.VecShkadov(1024, dev, "f32", None, L0=699.2, n_jets=10)
+        env.reset()
+        # from a DEVELOPED film (shkadov/init.py:13-27: 4000 uncontrolled action steps under inlet noise), not the flat one:
+        # the limiter branches and the noise amplification are what a trainer's steps run through
+        env.warmup(env.n_warmup_ref, torch.zeros((1024, 10), dtype=env.tdtype, device=dev))
+        amp = float((env.get_state()[:, 0] - 1.0).abs().amax(dim=1).mean())
+        a10 = torch.as_tensor(rng.uniform(-1, 1, (64, 1024, 10)), dtype=env.tdtype, device=dev)
+        k = [0]
+
+        def st_shk():
+            env.step(a10[k[0] % 64]); k[0] += 1
+        ms = timed_loop(env, st_shk, 50)
+        line("shkadov-v0 N=4096 10 jets B=1024 float32 (configs[2])", env, ms, 32.0 * env.nx * env.ndt_act * 1024,
+             {"ms_per_step_in_hip_graph": timed_graph(env, a10[0]), "inlet_noise": "drawn inside the step kernel (bcn_set_noise)",
+              "initial_state": "developed on the device: %d uncontrolled action steps under inlet noise; mean wave amplitude max|h-1| = %.3f"
+                               % (env.n_warmup_ref, amp),
+              "actions": "uniform(-1, 1) per replica, jet and step", "blown_up_replicas_after_timing": int((env.status & 2).bool().sum())})
+        env.close()
+
+    def leg_sloshing():
+        # sloshing (reference default grid) B=1024: 32 B per cell per timestep
+        env = V.VecSloshing(1024, dev, "f32", packaged_init("sloshing"))
+        env.reset()
+        ms = timed_loop(env, lambda: env.step(a1), 200)
+        line("sloshing-v0 N=200 B=1024 float32", env, ms, 32.0 * (env.nx + 2) * env.ndt_act * 1024,
+             {"ms_per_step_in_hip_graph": timed_graph(env, a1)})
+        env.close()
+
+    def leg_lorenz():
+        out.append(lorenz_line())
+
+    for leg in (leg_stop_rules, leg_headline_f64, leg_mixing_f32, leg_mixing_f64, leg_tall_grid, leg_burgers, leg_shkadov,
+                leg_sloshing, leg_lorenz):
+        try:      # one failing configuration must not cost the others (nor the headline: main() guards this whole function too)
+            leg()
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            import traceback
+            sys.stderr.write("bench.py: secondary leg %s failed:\n%s" % (leg.__name__, traceback.format_exc()))
+            out.append({"workload": leg.__name__[4:], "error": "%s: %s" % (type(e).__name__, e)})
     return out
+
+
+def lorenz_line(episodes=4):
+    """BASELINE configs[0]: lorenz-v0, single env, CPU (RK4 ODE -- plumbing, no GPU): whole 500-step episodes of the
+    host-only mirror (beacon_amd/lorenz.py, bit-exact against the reference's episodes: tests/test_host.py)."""
+    import numpy as np
+    from beacon_amd.lorenz import lorenz
+    env = lorenz()
+    rng = np.random.default_rng(0)
+    n, t0 = 0, time.perf_counter()
+    for _ in range(episodes):
+        env.reset()
+        done = False
+        while not done:
+            _, _, done, _, _ = env.step(np.int64(rng.integers(0, 3)))
+            n += 1
+    dt = time.perf_counter() - t0
+    return {"workload": "lorenz-v0 single env (configs[0]: CPU plumbing, no GPU kernel)", "value": n / dt, "unit": "env steps/s",
+            "ms_per_launch": 1e3 * dt / n, "kernel": "host (beacon_amd/lorenz.py)", "dtype": "f64", "steps": n,
+            "note": "%d episodes of %d action steps on one host core, random Discrete(3) actions" % (episodes, n // episodes)}
 
 
 def main():
@@ -560,6 +613,7 @@ def main():
         if dist.is_initialized():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         kern_ms = [s_.elapsed_time(e_) for s_, e_ in ev] if use_ev else [1e3 * elapsed / K] * K
+        timed_steps.own_elapsed = elapsed            # this rank's own wall time of the timed region (the return value is the max)
         return float(tt.item()), kern_ms, sweeps_all
 
     env = make_env(B)
@@ -578,8 +632,48 @@ def main():
             saved["state"] = env.get_state()[:min(os.cpu_count() or 1, B)].cpu().numpy().astype(np.float64)
 
     elapsed, kern_ms, sweeps_all = timed_steps(env, senv, acts, W, K, distc, keep_state)
+    own_elapsed = timed_steps.own_elapsed
     state_after_warmup = saved.get("state")
     cyc = env.get_counters().astype(np.float64)     # of the last step
+
+    # ---- who ran what: one record per rank, so that an N > 1 line proves its own topology ----
+    def rank_record():
+        rec = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "host": socket.gethostname(),
+               "replicas": B, "global_replica_range": [senv.lo, senv.hi],
+               "ms_per_launch": float(np.mean(kern_ms)), "ms_per_step_own_clock": 1e3 * own_elapsed / K,
+               "env_steps_per_s_own_clock": B * K / own_elapsed,
+               "jacobi_sweeps_timed": int(sum(int(x.sum().item()) for x in sweeps_all)),
+               "kernel": env.kernel_name}
+        if args.stub:
+            rec["device"] = "cpu (stub env)"
+        else:
+            pr = torch.cuda.get_device_properties(local_rank)
+            rec.update({"device_index": local_rank, "device_name": pr.name,
+                        "gcn_arch": getattr(pr, "gcnArchName", None), "compute_units": pr.multi_processor_count,
+                        "uuid": str(getattr(pr, "uuid", "")) or None,
+                        "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                                    getattr(pr, "pci_device_id", 0)) if hasattr(pr, "pci_bus_id") else None,
+                        "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")})
+        return rec
+    ranks = [rank_record()]
+    if dist.is_initialized():
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks[0])
+        ranks = gathered
+    topo = {"world_size": world, "backend": (args.backend if dist.is_initialized() else None),
+            "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else
+                        ("bench.py self-launch" if world_env is not None else "single process")}
+    if dist.is_initialized() and args.backend == "nccl" and not args.stub:
+        try:
+            topo["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001
+            topo["rccl_version"] = "unavailable: %s" % e
+    if not args.stub:
+        ids = [(r.get("host"), r.get("uuid") or r.get("pci") or r.get("device_index")) for r in ranks]
+        topo["distinct_devices"] = len(set(ids))
+        if world > 1 and not args.share_gpu and len(set(ids)) != world:
+            raise SystemExit("bench.py: %d ranks but only %d distinct devices (%s): one process per GPU is the contract"
+                             % (world, len(set(ids)), ids))
 
     def dist_path_lines():
         """The headline workload once more through the N > 1 code path on this one GPU: a process group of ONE rank over the
@@ -609,8 +703,13 @@ def main():
                               "mean_jacobi_sweeps_per_timestep": float(np.mean([x.float().mean().item() for x in sw2]))})
                 e2.close()
         finally:
-            dist.barrier()
-            dist.destroy_process_group()
+            # (no barrier on the way out of an exception: on a broken group it would mask the error that broke it)
+            try:
+                if sys.exc_info()[0] is None:
+                    dist.barrier()
+                dist.destroy_process_group()
+            except Exception as e2:
+                sys.stderr.write("bench.py: tearing down the one-rank process group failed: %s\n" % e2)
         return lines
 
     # N > 1, weak scaling: one more short timed loop with the GLOBAL batch of --batch replicas sharded over the ranks,
@@ -640,13 +739,36 @@ def main():
         kname = env.kernel_name
         cells = env.nx * env.ny
         sweeps_per_launch = float(np.mean([s.sum() for s in sw_np]))
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname, "avg_launch_ms": launch_s * 1e3,
-                "algorithmic_bytes_per_launch": sum(alg) / len(alg),
-                "note": "effective GB/s = SURVEY 8d algorithmic bytes / launch time (HIP events on the launch "
-                        "stream); a replica's state stays in registers/LDS inside the launch, so frac > 1 says that "
-                        "HBM is not the binding resource: see `binding` (VALU issue) and `hbm_measured`"}
-        tr = committed_profile(kname, "hbm_bytes_per_dispatch", args.dtype)
+        hbm_eff = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                   "algorithmic_bytes_per_launch": sum(alg) / len(alg),
+                   "note": "SURVEY 8d accounting: algorithmic bytes (20 values per cell and timestep + 3 per cell and Jacobi sweep) / "
+                           "launch time (HIP events on the launch stream).  A replica's state stays in registers / LDS inside the "
+                           "launch, so this EFFECTIVE figure exceeds the HBM peak: HBM is not the binding resource (`traffic`, "
+                           "`hbm_measured`); VALU issue is, and the top-level `frac` is that fraction"}
+        # binding resource: VALU issue.  Instructions per launch from the committed SQ_INSTS_VALU pass of the same command
+        # (PMC counters need rocprofv3), scaled by this run's sweeps per launch over the profile's, over THIS run's launch time
+        # (HIP events); without a committed profile of this kernel: the minimum-instruction count (7 VALU per cell and sweep).
+        grid_tag = "%d, %d," % (env.nx, env.ny)
+        vi = committed_profile(kname, "SQ_INSTS_VALU", args.dtype, grid_tag)
+        min_ach = MIN_VALU_PER_CELL_SWEEP * cells / 64.0 * sweeps_per_launch / launch_s
+        roof = {"bound": "valu_issue", "achieved": min_ach, "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instructions/s",
+                "frac": min_ach / VALU_ISSUE_PEAK, "traffic": None, "kernel": kname, "avg_launch_ms": launch_s * 1e3,
+                "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+                "instructions": "lower bound: %d VALU instructions per cell and sweep (no committed SQ_INSTS_VALU profile of this kernel)"
+                                % MIN_VALU_PER_CELL_SWEEP,
+                "min_instr": {"achieved": min_ach, "frac": min_ach / VALU_ISSUE_PEAK,
+                              "note": "%d VALU instructions per cell and Jacobi sweep, nothing else counted" % MIN_VALU_PER_CELL_SWEEP}}
+        if vi and vi.get("sweeps_per_dispatch"):
+            insts = vi["value"] * sweeps_per_launch / vi["sweeps_per_dispatch"]
+            roof.update({"achieved": insts / launch_s, "frac": insts / launch_s / VALU_ISSUE_PEAK,
+                         "instructions": "SQ_INSTS_VALU of profiles/%s (%.4g per dispatch at %.4g sweeps), scaled to this run's %.4g "
+                                         "sweeps per launch" % (vi["source"], vi["value"], vi["sweeps_per_dispatch"], sweeps_per_launch),
+                         "instructions_measured_in_this_run": False, "launch_time_measured_in_this_run": True,
+                         "source": "profiles/" + vi["source"]})
+            sys.stderr.write("bench.py: VALU / HBM counters rescaled from profiles/%s (%.4g sweeps per dispatch there, %.4g per "
+                             "launch in this run)\n" % (vi["source"], vi["sweeps_per_dispatch"], sweeps_per_launch))
+        roof["hbm_effective"] = hbm_eff
+        tr = committed_profile(kname, "hbm_bytes_per_dispatch", args.dtype, grid_tag)
         if tr:
             roof["traffic"] = tr["value"]
             roof["hbm_measured"] = {"bytes_per_launch": tr["value"], "GB/s": tr["value"] / launch_s / 1e9,
@@ -661,27 +783,9 @@ def main():
         if cyc[:, 1].sum() > 0:
             share = float(cyc[:, 0].sum() / cyc[:, 1].sum())
             pb = 12.0 / 4 * esz * cells * float(sw_np[-1].sum())
-            roof["poisson"] = {"time_share": share, "achieved": pb / (share * kern_ms[-1] * 1e-3) / 1e9, "unit": "GB/s",
-                               "frac": pb / (share * kern_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            roof["poisson"] = {"time_share": share, "hbm_effective_GBs": pb / (share * kern_ms[-1] * 1e-3) / 1e9,
+                               "hbm_effective_frac": pb / (share * kern_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "cycles_per_replica_sweep": float(cyc[:, 0].sum() / max(1.0, float(sw_np[-1].sum())))}
-        # binding resource: VALU issue.  Instructions from the committed SQ_INSTS_VALU pass, scaled to this run's
-        # sweeps; the minimum-instruction variant counts 7 VALU instructions per cell and sweep.
-        vi = committed_profile(kname, "SQ_INSTS_VALU", args.dtype)
-        binding = {"bound": "valu_issue", "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instructions/s",
-                   "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
-                   "min_instr_achieved": MIN_VALU_PER_CELL_SWEEP * cells / 64.0 * sweeps_per_launch / launch_s}
-        binding["min_instr_frac"] = binding["min_instr_achieved"] / VALU_ISSUE_PEAK
-        if vi and vi.get("sweeps_per_dispatch"):
-            insts = vi["value"] * sweeps_per_launch / vi["sweeps_per_dispatch"]
-            binding.update({"achieved": insts / launch_s, "frac": insts / launch_s / VALU_ISSUE_PEAK,
-                            "source": "profiles/" + vi["source"], "measured_in_this_run": False,
-                            "profile_sweeps_per_dispatch": vi["sweeps_per_dispatch"],
-                            "this_run_sweeps_per_launch": sweeps_per_launch,
-                            "note": "SQ_INSTS_VALU of the committed profile, scaled by this run's sweeps per launch over the "
-                                    "profile's, divided by THIS run's launch time"})
-            sys.stderr.write("bench.py: VALU / HBM counters rescaled from profiles/%s (%.4g sweeps per dispatch there, %.4g per "
-                             "launch in this run)\n" % (vi["source"], vi["sweeps_per_dispatch"], sweeps_per_launch))
-        roof["binding"] = binding
         metric = "aggregate env steps/sec, rayleigh-v0 batch=%d%s %dx%d" % (args.batch, "/GPU" if args.scaling == "weak" else " global", env.nx, env.ny)
         out = {
             "metric": metric,
@@ -695,6 +799,8 @@ def main():
                        "mean_jacobi_sweeps_per_timestep": mean_sw, "parallelism": "replica-sharded x%d" % world + (" (rehearsal: all ranks on cuda:0)" if args.share_gpu else ""),
                        "kernel": kname},
             "roofline": roof,
+            "ranks": ranks,
+            "topology": topo,
         }
         out["solver"] = {"conv_plan": "3 (float32 default: extrapolated residual plan, late stops repeated under the proven plan)"
                          if args.dtype == "f32" else "1 (float64 default: proven plan)",
@@ -703,15 +809,30 @@ def main():
             out["strong"] = strong
         # (the N > 1 rehearsal BEFORE the CPU legs: the C oracle's OpenMP workers keep spinning on every host core after
         #  their parallel regions, and the blocking gather's host side then measured 2 ms per step late)
+        # Nothing below may cost the headline that is already measured: a failure of a secondary leg (RCCL rendezvous of the
+        # one-rank rehearsal, a secondary configuration, the CPU legs) becomes an {"error": ...} entry and the line is printed.
         sec = []
+
+        def guarded(what, fn):
+            try:
+                return fn()
+            except Exception as e:      # noqa: BLE001 -- reported in the line
+                import traceback
+                sys.stderr.write("bench.py: %s failed:\n%s" % (what, traceback.format_exc()))
+                sec.append({"workload": what, "error": "%s: %s" % (type(e).__name__, e)})
+                return None
         if world == 1 and not args.no_secondary and not args.stub and not distc:
-            sec = dist_path_lines()
+            sec += guarded("headline workload through the N > 1 path (one rank over %s)" % args.backend, dist_path_lines) or []
         if world == 1 and not args.no_cpu and not args.stub:
-            out["cpu_baseline"] = cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H))
+            cpu = guarded("cpu_baseline", lambda: cpu_legs(state_after_warmup, acts_np[W:], dict(L=L, H=H)))
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
         if world == 1 and not args.no_secondary and not args.stub:
             env.close()
-            sec += secondary_lines(dev, acts_np, W, init, (L, H))
+            sec += guarded("secondary configurations", lambda: secondary_lines(dev, acts_np, W, init, (L, H))) or []
+        if sec:
             out["secondary"] = sec
+        if world == 1 and not args.no_secondary and not args.stub:
             for d in sec:      # the figure under the PROVEN stop rule next to the headline
                 if d.get("options") == {"conv_plan": 1} and d.get("dtype") == args.dtype:
                     out["config"]["proven_stop_rule"] = {"ms_per_step": d["ms_per_launch"], "value": d["value"],

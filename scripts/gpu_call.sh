@@ -12,8 +12,11 @@ step() { # name, timeout, command...
   local rc=$?
   echo "== $name rc=$rc" | tee -a $OUT/steps.log
   if [ $rc -ge 124 ]; then echo "killed: stop" | tee -a $OUT/steps.log; exit $rc; fi
+  if [ $rc -ne 0 ] && [ $rc -gt $worst ]; then worst=$rc; fi      # the call ends with the worst code of its steps
+  if [ $rc -ne 0 ] && [ "$name" = tests ]; then echo "tests failed: the later steps would measure a broken build: stop" | tee -a $OUT/steps.log; exit $rc; fi
   return $rc
 }
+worst=0
 export BEACON_NO_BUILD=1
 for what in "$@"; do
   case $what in
@@ -41,4 +44,4 @@ for what in "$@"; do
     *) echo "unknown step $what" ;;
   esac
 done
-exit 0
+exit $worst

@@ -2401,3 +2401,79 @@ def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+# ---- on-demand kernels: first-use self-check ---------------------------------------------
+def _fuzz_ids():
+    from beacon_amd import jit
+    return ["%s-%dx%d-%s" % (("rayleigh", "mixing")[k[3]], k[0], k[1], "f64" if k[2] else "f32") for k in jit.fuzz_grid_keys()]
+
+
+@pytest.mark.parametrize("idx", range(22), ids=_fuzz_ids() if torch.cuda.is_available() else None)
+def test_jit_fuzzed_grids_agree_with_the_generic_kernel(idx):
+    """22 random domain sizes (seeded; the reference takes any L, H: rayleigh.py:20-27, mixing.py:20-28) across every
+    kernel family -- one / two rows per lane and the hybrid, float32 and float64 -- each through the comparison that guards a
+    plugin's first use (beacon_amd/jit.py: six timesteps, plain launch and ticket scheduler, against the generic kernel):
+    float64 1e-9 with sweep counts within 1, float32 2e-4 with counts within max(3, 2 %).  (Promoted from
+    scripts/fuzz_grids.py; the plugins are compiled by __graft_entry__.build().)"""
+    from beacon_amd import jit
+    L, H, f64, kind = jit.fuzz_grids()[idx]
+    dt = "f64" if f64 else "f32"
+    mk = (lambda B: V.VecRayleigh(B, DEV, dt, None, L=L, H=H)) if kind == 0 else (lambda B: V.VecMixing(B, DEV, dt, L=L, H=H))
+    env = mk(2)             # the constructor itself runs the self-check of a plugin that has no verdict yet
+    p = getattr(env, "_plugin", None)
+    assert p is not None and p.verified is True, "no verified plugin for this grid"
+    env.close()
+    ok, rep = jit.compare_with_generic(mk, kind, f64)       # and once more here, whatever the marker files say
+    assert ok, rep
+
+
+def test_jit_self_check_refuses_a_broken_plugin_and_keeps_the_generic_kernel():
+    """A deliberately wrong plugin (csrc/jit/ns2d_jit.hip built with -DBCN_JIT_BREAK: the kernel runs with 1.5 dt) must not be
+    attached: the first env that asks for it compares it with the generic kernel, warns, leaves a `.bad` marker, and steps on
+    the generic kernel with the generic kernel's results; a later env does not even run the comparison."""
+    import warnings
+    from beacon_amd import jit
+
+    class Broken(V.VecRayleigh):
+        _plugin_defs = {"BCN_JIT_BREAK": 1}
+    path = jit.build_plugin(75, 50, True, 0, extra_defs=Broken._plugin_defs)
+    assert path is not None, "the broken test plugin was not built (run __graft_entry__.build())"
+    for mark in (".ok", ".bad"):
+        if os.path.exists(path + mark):
+            os.remove(path + mark)
+    jit._LOADED.pop((75, 50, True, 0, tuple(sorted(Broken._plugin_defs.items()))), None)
+    try:
+        with pytest.warns(UserWarning, match="DISAGREES with the generic kernel"):
+            env = Broken(2, DEV, "f64", None, L=1.5, H=1.0)
+        assert getattr(env, "_plugin", None) is None and os.path.exists(path + ".bad")
+        ref = V.VecRayleigh(2, DEV, "f64", None, L=1.5, H=1.0)
+        ref.set_variant(0)
+        a = np.random.default_rng(1).uniform(-1, 1, (2, 10))
+        for e in (env, ref):
+            e.set_ndt_act(4)
+            e.reset()
+            e.set_state(jit._seeded_rayleigh_state(e))
+            e.step(a)
+            e.check_status()
+        assert env.kernel_name == "ns2d_generic_step"
+        assert torch.equal(env.get_state(), ref.get_state()) and torch.equal(env.sweeps, ref.sweeps)
+        env.close()
+        ref.close()
+        # the verdict is remembered: a later env (a later process: the cache of loaded plugins cleared) skips the plugin at once
+        jit._LOADED.clear()
+        with pytest.warns(UserWarning, match="failed its self-check earlier"):
+            env2 = Broken(2, DEV, "f64", None, L=1.5, H=1.0)
+        assert getattr(env2, "_plugin", None) is None
+        env2.close()
+        # the sound plugin of the same grid is unaffected
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            good = V.VecRayleigh(2, DEV, "f64", None, L=1.5, H=1.0)
+        assert good._plugin.verified is True
+        good.close()
+    finally:
+        for mark in (".ok", ".bad"):
+            if os.path.exists(path + mark):
+                os.remove(path + mark)
+        jit._LOADED.clear()

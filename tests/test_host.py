@@ -213,7 +213,7 @@ B, NA = 6, 4                                          # replicas per rank, episo
 G = B * world
 gen = torch.Generator().manual_seed(3)
 acts = torch.rand((14, G, 3), generator=gen)
-stp0 = torch.tensor([0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3], dtype=torch.int32)   # staggered episode ends
+stp0 = (torch.arange(G) %% 4).to(torch.int32)            # staggered episode ends
 
 
 def script(env, sharded):
@@ -283,20 +283,75 @@ print("rank", rank, "ok")
 """
 
 
+def _run_sharded_script(tmp_path, world, extra_env=None):
+    script = tmp_path / "worker2.py"
+    script.write_text(_WORKER2 % (ROOT, ROOT))
+    s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
 def test_sharded_env_masks_auto_reset_and_overlapped_gather_gloo_world2(tmp_path):
     """ShardedVecEnv.reset(mask) / step(mask=) / reset_done() and the double-buffered, asynchronous
     gather (step_async) over two processes -- every output of a 12-step script with staggered episode ends, single-env
     resets, a masked step and auto-resets equals, bit for bit, ONE process stepping the global batch."""
-    script = tmp_path / "worker2.py"
-    script.write_text(_WORKER2 % (ROOT, ROOT))
+    _run_sharded_script(tmp_path, 2)
+
+
+def test_sharded_env_masks_auto_reset_and_overlapped_gather_gloo_world8(tmp_path):
+    """the same script of trainer calls at the world size of the metric (8 ranks, 48 replicas), with the
+    call-shape check of ShardedVecEnv switched on (BEACON_DIST_CHECK=1: every rank is in the same call, with a mask
+    placeholder wherever rank 0 passes a mask)."""
+    _run_sharded_script(tmp_path, 8, {"BEACON_DIST_CHECK": "1"})
+
+
+def test_sharded_env_rejects_bad_buffer_counts_and_mismatched_calls(tmp_path):
+    """BEACON_NBUF / nbuf are validated in the constructor; a rank that passes mask=None where rank 0 passes a mask
+    is caught by check_calls instead of meeting rank 0 in the wrong collective."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from beacon_amd.dist import ShardedVecEnv
+    from cpu_env import CpuVecEnv
+    with pytest.raises(ValueError, match="at least 2"):
+        ShardedVecEnv(CpuVecEnv(4), nbuf=0)
+    os.environ["BEACON_NBUF"] = "three"
+    try:
+        with pytest.raises(ValueError, match="not an integer"):
+            ShardedVecEnv(CpuVecEnv(4))
+    finally:
+        del os.environ["BEACON_NBUF"]
+    assert ShardedVecEnv(CpuVecEnv(4), nbuf=4).NBUF == 4 and ShardedVecEnv(CpuVecEnv(4)).NBUF == 3
+    worker = tmp_path / "worker3.py"
+    worker.write_text(r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+from beacon_amd.dist import ShardedVecEnv
+from cpu_env import CpuVecEnv
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+senv = ShardedVecEnv(CpuVecEnv(4), check_calls=True)
+senv.reset()
+try:
+    senv.step(torch.zeros((8, 3)) if rank == 0 else None, mask=torch.ones(8, dtype=torch.uint8) if rank == 0 else None)
+    print("rank", rank, "no error")
+except RuntimeError as e:
+    assert "disagree on the call" in str(e), e
+    print("rank", rank, "caught")
+dist.destroy_process_group()
+""" % (ROOT, ROOT))
     s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+    procs = [subprocess.Popen([sys.executable, str(worker)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, o
-        assert "rank %d ok" % r in o
+        assert p.returncode == 0 and "rank %d caught" % r in o, o
 
 
 def test_bench_self_launch_and_scalings_on_cpu_stub():
@@ -320,6 +375,32 @@ def test_bench_self_launch_and_scalings_on_cpu_stub():
             assert st["global_batch"] == 16 and st["replicas_per_gpu"] == 8 and st["steps"] == 3 and st["value"] > 0
         else:
             assert "strong" not in d
+
+
+def test_bench_world8_rehearsal_on_cpu_stub_carries_eight_rank_records():
+    """`bench.py --gpus 8 --stub --backend gloo`, weak and strong: ONE line whose `ranks` block holds one
+    record per rank (distinct processes, contiguous replica ranges covering the global batch, own clocks) and a `topology`
+    block -- what makes the driver's N = 8 line self-evidencing (there with device uuids / PCI ids and the RCCL version)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    for scaling, per_gpu, glob in (("weak", 16, 128), ("strong", 2, 16)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                            "--batch", "16", "--scaling", scaling, "--stub", "--backend", "gloo"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["global_batch"] == glob
+        rk = d["ranks"]
+        assert [x["rank"] for x in rk] == list(range(8)) and len({x["pid"] for x in rk}) == 8
+        assert [x["global_replica_range"] for x in rk] == [[i * per_gpu, (i + 1) * per_gpu] for i in range(8)]
+        assert all(x["replicas"] == per_gpu and x["ms_per_step_own_clock"] > 0 and x["jacobi_sweeps_timed"] > 0 for x in rk)
+        assert d["topology"] == {"world_size": 8, "backend": "gloo", "launcher": "bench.py self-launch"}
+        # the job's clock is the slowest rank's: no rank's own clock is above it
+        assert max(x["ms_per_step_own_clock"] for x in rk) <= d["ms_per_step"] * (1 + 1e-9)
+        if scaling == "weak":
+            assert d["strong"]["global_batch"] == 16 and d["strong"]["replicas_per_gpu"] == 2
 
 
 def test_bench_force_dist_runs_the_collectives_with_one_rank_on_cpu_stub():
