@@ -9,6 +9,13 @@
 
 #define BCN_WAVE 64
 
+// Guard of the extrapolating residual plan (bcn_set_option "conv_plan" 3; ns2d_fast_impl.h).  The reference's norm
+// err_k = d_k' (I + G) d_k of the Jacobi increments can GROW from one sweep to a later one -- by at most
+// C = max_m || W^(1/2) J^m W^(-1/2) ||^2 = 1.0300 over every grid, cell aspect ratio and boundary type computed by
+// scripts/weighted_norm_bound.py (1.0166 in one sweep, the maximum after 4..6 sweeps).  So an evaluation that directly
+// follows skipped sweeps proves that none of them passed the test (err_j <= tol) exactly when it finds err > C tol.
+#define BCN_CONV_GUARD 1.035
+
 __attribute__((visibility("default"))) void bcn_set_error(const char* fmt, ...);
 
 #define BCN_HIP(call)                                                                      \

@@ -38,6 +38,7 @@ struct NS2DEnv : bcn_env_s {
   DevBuf obs_hist, a_last, ia_last, stpbuf, sweepbuf, orderbuf, schedbuf, fscrbuf, statusbuf;
   int32_t* status_int = nullptr;   // per-replica status words when the caller passes no status_dev
   bool fast_ok = false;
+  bool guard_holds() const { return a.nx >= 48 && a.ny >= 48; }
 
   int init() {
     const size_t per = (size_t)batch * a.ncell * sizeof(real);
@@ -88,16 +89,18 @@ struct NS2DEnv : bcn_env_s {
       a.fscr = static_cast<real*>(fscrbuf.p);
     }
     variant = fast_ok ? 1 : 0;
-    // float64: the proven plan (exactly the reference's stop sweep); float32: the extrapolating plan, guarded -- a stop it
-    // did not foresee is repeated under the proven plan (ns2d_fast_impl.h)
-    a.conv_plan = sizeof(real) == 4 ? 3 : 1;
-    if (const char* e = getenv("BCN_CONV_PLAN")) a.conv_plan = atoi(e);
-    // rayleigh float32: a solve opens with double sweeps up to 7/8 of the previous timestep's count (measured on the bench
-    // workload: 5/8, 6/8, 7/8 -> 800, 791, 778 cycles per sweep; at 7/8 about 30 of 102 400 solves per step land behind
-    // their stop sweep and are repeated); mixing's counts drop by up to 9x from one timestep to the next: off; the float64
-    // kernels are built without the jump (ns2d_fast_impl.h)
-    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 7 : 0;
-    if (const char* e = getenv("BCN_SPEC_START")) a.spec_start = atoi(e);
+    // both precisions: the extrapolating plan with PROVEN landings (plan 3: every stop sweep is the reference's, ns2d_fast_impl.h).
+    // (Until round 5 float64 ran the lower-bound plan 1: plan 3's landings were not yet verified by a bound.)
+    a.conv_plan = 3;
+    // the landing test of plans 2 / 3 rests on a bound (BCN_CONV_GUARD, bcn_common.h) that holds for grids with no side below 48
+    // cells -- every grid the reference can construct (nx = 50 L, ny = 50 H, L, H >= 1); smaller ones: the proven plan
+    if (!guard_holds()) a.conv_plan = 1;
+    // rayleigh float32: a solve opens with double sweeps up to 6/8 of the previous timestep's count.  The landing must find the
+    // residual above BCN_CONV_GUARD * tol (ns2d_fast_impl.h: that proves that no skipped sweep passed) or the solve is repeated
+    // without the guess -- measured on the bench workload, repeats per step of 102 400 solves / cycles per sweep: 7/8 27 252 / 916,
+    // 6/8 2 021 / 818, 5/8 205 / 827, 4/8 5 / 837, off 0 / 888 (the unverified rule of round 3 landed at 7/8: 740).  mixing's
+    // counts drop by up to 9x from one timestep to the next: off; the float64 kernels are built without the jump
+    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 6 : 0;
     return BCN_OK;
   }
   ~NS2DEnv() override {
@@ -124,17 +127,23 @@ struct NS2DEnv : bcn_env_s {
   int set_state(const void* buf, int is_device, hipStream_t s) override {
     return copy_state(const_cast<void*>(buf), is_device, s, false);
   }
-  int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; launched = nullptr; return variant; }
+  int set_variant(int v) override { variant = (v == 1 && fast_ok) ? 1 : 0; host.launched = nullptr; return variant; }
   void set_mask(const uint8_t* m) override { a.mask = m; }
   int set_sched(int mode, int grid, int q, int lpt_min_batch) override {
     a.sched_mode = mode; a.sched_grid = grid; a.sched_q_user = q; a.lpt_min_batch = lpt_min_batch;
     return BCN_OK;
   }
   int set_option(const char* name, int value) override {
-    if (!strcmp(name, "conv_plan") && value >= 0 && value <= 3) { a.conv_plan = value; return BCN_OK; }
+    if (!strcmp(name, "conv_plan") && value >= 0 && value <= 3) {
+      if (value >= 2 && !guard_holds()) { bcn_set_error("conv_plan %d needs a grid with no side below 48 cells (%dx%d): plans 0, 1 only", value, a.nx, a.ny); return BCN_ERR_ARG; }
+      a.conv_plan = value;
+      return BCN_OK;
+    }
     if (!strcmp(name, "plan_overshoot") && value >= 0 && value <= 64) { a.plan_overshoot = value; return BCN_OK; }
     if (!strcmp(name, "verify_conv")) { a.verify_conv = value ? 1 : 0; return BCN_OK; }
     if (!strcmp(name, "spec_start") && value >= 0 && value <= 16) { a.spec_start = value; return BCN_OK; }
+    if (!strcmp(name, "sched_tail") && value >= 0 && value <= 1024) { host.sched_tail = value; return BCN_OK; }
+    if (!strcmp(name, "generic_threads") && (value == 0 || value == 256 || value == 1024)) { host.generic_nt = value; return BCN_OK; }
     return bcn_env_s::set_option(name, value);
   }
   int get_counters(uint64_t* host, hipStream_t s) override {
@@ -156,15 +165,15 @@ struct NS2DEnv : bcn_env_s {
       a.fscr_stride = scratch_elems;
     }
     plugin = reinterpret_cast<plugin_fn>(fn);
-    fast_ok = true; variant = 1; launched = nullptr;
+    fast_ok = true; variant = 1; host.launched = nullptr;
     return BCN_OK;
   }
-  const char* launched = nullptr;   // name of the kernel the last step dispatched
+  NS2DHost host;   // launcher-side state: kernel name of the last step, options that no kernel reads
   const char* kernel_name() const override {
-    return launched ? launched : (variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step");
+    return host.launched ? host.launched : (variant == 1 ? "ns2d_fast_step" : "ns2d_generic_step");
   }
   int launch(hipStream_t s) {
-    a.launched = &launched;
+    a.host = &host;
     if (variant == 1 && plugin) {
       // BCN_ERR_UNSUPPORTED: the batch does not fit the plugin's addressing (ns2d_fast4_impl.h: 32-bit offsets from a
       // replica's u): the generic kernel takes the step
@@ -297,6 +306,11 @@ struct Env1D : bcn_env_s {
   }
   const char* kernel_name() const override { return kname; }
   void set_mask(const uint8_t* m) override { a.mask = m; }
+  int set_option(const char* name, int value) override {
+    if (!strcmp(name, "cells_per_thread") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { a.force_k = value; return BCN_OK; }
+    if (!strcmp(name, "one_wave") && (value == 0 || value == 1)) { a.one_wave = value; return BCN_OK; }
+    return bcn_env_s::set_option(name, value);
+  }
 };
 
 template <typename real>

@@ -40,6 +40,9 @@ struct Env1DArgs {
   uint8_t* done;
   uint8_t* trunc;
   int32_t* status;
+  // host side only (launchers), by bcn_set_option:
+  int force_k = 0;          // "cells_per_thread": 1, 2, 4 or 8 cells per thread (0 = chosen from grid and batch: pick_k)
+  int one_wave = 1;         // "one_wave": grids up to 512 cells as ONE wave per replica with DPP halos (0: the LDS-halo kernels)
 };
 
 // Philox4x32-10 (Salmon et al., SC'11): four 32-bit words per (counter, key)

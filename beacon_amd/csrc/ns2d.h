@@ -6,6 +6,15 @@
 #pragma once
 #include "bcn_common.h"
 
+// What only the launchers read and write, kept OUT of the kernel argument block: a field more in NS2DArgs shifts the kernarg
+// offsets, and hipcc's schedule of the register-saturated kernels reacts to that (round 5: 8 bytes more = 18 761 changed lines
+// of ISA in ns2d_fast.hip).
+struct NS2DHost {
+  const char* launched = nullptr;   // name of the kernel the last step dispatched
+  int sched_tail = 0;               // bcn_set_option "sched_tail": short chunks that end a step of the ticket scheduler (0 = default 6)
+  int generic_nt = 0;               // bcn_set_option "generic_threads": threads per workgroup of the generic kernel, 256 / 1024 (0 = by grid size)
+};
+
 template <typename real>
 struct NS2DArgs {
   int nx, ny, sx, ncell;
@@ -56,10 +65,10 @@ struct NS2DArgs {
   int plan_overshoot = 0;   // TEST HOOK: sweeps added to every skip of the extrapolating plan (provokes late stops: tests of conv_plan 3)
   int spec_start = 0;       // first evaluation of a solve at spec_start/8 of the previous timestep's sweep count (0: at sweep 1): ns2d_fast_impl.h
   int verify_conv = 0;      // 1: evaluate the Jacobi residual after every sweep and flag BCN_ST_PLAN if the evaluation plan
-                            //    of the register-resident kernels would have skipped a sweep that passes the test (BCN_VERIFY_CONV=1)
-  int sched_mode = -1;      // per-handle overrides of the BCN_SCHED* defaults (bcn_set_sched): -1 / 0 = default
+                            //    of the register-resident kernels would have skipped a sweep that passes the test
+  int sched_mode = -1;      // scheduling of the register-resident kernels (bcn_set_sched): -1 / 0 = default
   int sched_grid = 0, sched_q_user = 0, lpt_min_batch = 0;
-  const char** launched;    // host side: receives the name of the kernel the launcher dispatched (may be NULL)
+  NS2DHost* host;           // host side only (never read by a kernel; may be NULL): see NS2DHost
   real* fscr;               // per-workgroup field scratch of the register-resident kernels whose u, v, T do not
   size_t fscr_stride;       //   fit LDS (float64 128x64): [slots][fscr_stride] elements, slot = workgroup index
 };

@@ -79,12 +79,10 @@ struct Fast4Geom {
 template <int NX, int NW, int U, class LD, class ST>
 __device__ __forceinline__ void f4_cells(int w, int tx, int j_lo, int j_hi, LD&& ld, ST&& st) {
   constexpr int CPL = (NX + BCN_WAVE - 1) / BCN_WAVE;
-#ifndef BCN_F4_NO_LAUNDER
   // the lane's indices are recomputed in every phase (a few VALU instructions): left to itself hipcc hoists them out of
   // the timestep loop, keeps them live across the Poisson solve -- where every register is taken -- and reloads them from
   // scratch at each use
   asm volatile("" : "+v"(tx));
-#endif
   for (int jb = j_lo + w; jb <= j_hi; jb += NW * U) {
     decltype(ld(0, 0)) vals[U][CPL];
 #pragma unroll
@@ -175,21 +173,8 @@ __device__ __forceinline__ void f4_sweep(real (&Pv)[R + 1][RPL], const real (&Bv
   // that an evaluated sweep finds both halos complete when it starts
   constexpr int PB = EV ? -1 : (RC >= 2) ? (RC / 2 > 1 ? RC / 2 : 1) : (DIRB ? 1 : 0);
   real hf[RPL], hl[RPL];
-#if defined(BCN_F4_NOBAR) || defined(BCN_F4_NOLDS)   // timing experiments only (wrong results): plain sweeps without ...
-#ifdef BCN_F4_NOBAR
-#define BCN_F4_SYNC() if (EV) __syncthreads()
-#else
-#define BCN_F4_SYNC() __syncthreads()
-#endif
-#ifdef BCN_F4_NOLDS
-  constexpr bool XCH = EV;
-#else
-  constexpr bool XCH = true;
-#endif
-#else
 #define BCN_F4_SYNC() __syncthreads()
   constexpr bool XCH = true;
-#endif
   if (PB == 0) BCN_F4_SYNC();
 #pragma unroll
   for (int r = 0; r < RPL; r++) hf[r] = XCH ? first_rd[r] : real(0);
@@ -345,14 +330,6 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
   struct alignas(2 * sizeof(real)) F4YZ { real y, z; };   // aW, aS of a cell side by side: one LDS access in the walk
   F4YZ* TYZ = reinterpret_cast<F4YZ*>(TX + ((BR * P + 1) & ~1));
 
-#ifdef BCN_F4_PTR64   // experiment: plain 64-bit addresses per lane and field
-  real* __restrict__ u = A.u + off;
-  real* __restrict__ v = A.v + off;
-  real* __restrict__ p = A.p + off;
-  real* __restrict__ S = A.S + off;
-  real* __restrict__ us = A.us + off;
-  real* __restrict__ vs = A.vs + off;
-#else
   // (the descriptor must be provably wave-uniform, or hipcc wraps every access in a waterfall loop: b comes out of LDS in
   //  the ticket scheduler)
   const int bu = __builtin_amdgcn_readfirstlane(b);
@@ -360,7 +337,6 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
   const F4Field<real> u{rs, 0}, v{rs, (int)((A.v - A.u) * (long)sizeof(real))}, p{rs, (int)((A.p - A.u) * (long)sizeof(real))},
       S{rs, (int)((A.S - A.u) * (long)sizeof(real))}, us{rs, (int)((A.us - A.u) * (long)sizeof(real))},
       vs{rs, (int)((A.vs - A.u) * (long)sizeof(real))};
-#endif
 
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned long long t_jac = 0, n_eval = 0, n_late = 0, n_redo = 0;
@@ -466,9 +442,6 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
     __syncthreads();
     BCN_F4_PH(0)
 
-#ifndef BCN_F4_FUSE_RHS   // 1: predictor and Poisson rhs in ONE pass over the fields (below); 0: two passes (the rhs re-reads u*, v*)
-#define BCN_F4_FUSE_RHS 1
-#endif
     auto pred_load = [&](int j, int i) {
       const int c = j * SX + i;
       F4Pred<real> q;
@@ -503,7 +476,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         vs_o = vc + A.dt * (diff - conv - pres + q.s);
       }
     };
-    if constexpr (BCN_F4_FUSE_RHS && CPL <= 2) {
+    if constexpr (CPL <= 2) {
       // ---- predictor (rayleigh.py:370-407 / mixing.py:381-416) AND Poisson rhs (rayleigh.py:424-426) in one pass ----
       // The rhs of a cell needs u* of its east neighbour and v* of its north neighbour.  With lanes along x the east value is
       // the next lane's (one DPP move; the last lane's is the first lane's second column) -- and with the rows dealt to the
@@ -674,9 +647,9 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
     //    sweep can pass the test: those sweeps run without residual, reduction and test.
     //  2: the same extrapolation on the weighted sum itself (not proven convex; it is when the residual hovers within the
     //    weights' 10 % of tol for a hundred sweeps, where plan 1 cannot skip anything), one sweep and 1/16 short of the estimate.
-    //  3 (float32 default): plan 2, guarded: a passing evaluation that directly follows skipped sweeps is a stop the plan did
-    //    not foresee ("late stop": counted) -- the solve starts from phi = 0 and its rhs is still in registers, so it is simply
-    //    repeated under plan 1.
+    //  3 (float32 default): plan 2 with PROVEN landings: the first evaluation behind skipped sweeps must find the residual above
+    //    BCN_CONV_GUARD * tol -- then none of them passed (bcn_common.h) -- and the plan aims there; a landing below it is
+    //    counted ("late stop") and the solve -- it starts from phi = 0 and its rhs is still in registers -- repeated under plan 1.
     int plan = A.conv_plan;
     for (;;) {
 #pragma unroll
@@ -686,7 +659,10 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
       for (int k = tid; k < G::HAL; k += NT) hal[k] = 0;   // both parities of the exchange buffer start from phi = 0
       __syncthreads();
       itp = 0; par = 0;
-      const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+      // tolL: what a landing evaluation -- the first one behind skipped sweeps -- must exceed for the skip to be verified: under
+      // plan 3 BCN_CONV_GUARD * tol, which proves that no skipped sweep passed (bcn_common.h); under plan 2 tol itself
+      const real tolL = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
+      const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)tolL * 1.003f);
       int k_prev = -1, skip_left = 0;
       float l2u_prev = 0, l2w_prev = 0;
       constexpr int JMAX = 256;
@@ -696,7 +672,8 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
         /* the reference tests the sweep count FIRST: a solve that reaches sweep itmax + 1 overflows even if that sweep passes */  \
         /* (rayleigh.py:451-454, in front of the loop condition) */                                                                \
         if (itp > A.itmax) { status |= BCN_ST_ITMAX; break; }                                                                      \
-        if (!(err > A.tol)) {                                                                                                      \
+        /* a landing (the sweep before this one was not evaluated) that does not clear tolL leaves the skipped sweeps unverified */ \
+        if (!(err > A.tol) || (plan >= 2 && !A.verify_conv && itp >= 2 && k_prev != itp - 2 && !(err > tolL))) {                   \
           if (skip_left > 0) status |= BCN_ST_PLAN;                                                                                \
           break;                                                                                                                   \
         }                                                                                                                          \
@@ -993,7 +970,7 @@ int launch_fast4_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
     hipLaunchKernelGGL(ks, dim3(sp.grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, a.ndt_act / q);
     BCN_HIP(hipGetLastError());
-    if (a.launched) *a.launched = "ns2d_fast4_sched";
+    if (a.host) a.host->launched = "ns2d_fast4_sched";
     return BCN_OK;
   }
   if (a.sched_ctl) BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));   // cycle counters
@@ -1002,7 +979,7 @@ int launch_fast4_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   if (ns2d_first_on_device(set)) BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   BCN_HIP(hipGetLastError());
-  if (a.launched) *a.launched = "ns2d_fast4_step";
+  if (a.host) a.host->launched = "ns2d_fast4_step";
   return BCN_OK;
 }
 

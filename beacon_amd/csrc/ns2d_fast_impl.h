@@ -43,8 +43,10 @@
 #ifndef BCN_PDG
 #define BCN_PDG 8    // global fields, diagonals ahead.  Round 3 (T through flat pointers): 4 / 8 / 12 -> 52.9 / 52.1 / 51.3 ms per step
                      // (rayleigh 128x64 float64); round 4 (global pointers): 4 / 8 / 10 / 12 / 16 / 20 -> 53.0 / 51.2 / 51.9 / 52.0 / 51.9 / 61.0.
-                     // (6 is NOT a valid depth: the solve stopped converging -- unexplained; use the measured values only)
+                     // (measured depths only: an intermediate round-4 build with generic pointers stopped converging at a depth of 6)
 #endif
+static_assert(BCN_PDG == 4 || BCN_PDG == 8 || BCN_PDG == 10 || BCN_PDG == 12 || BCN_PDG == 16 || BCN_PDG == 20,
+              "BCN_PDG: only the prefetch depths that were measured AND verified against the oracle (4, 8, 10, 12, 16, 20)");
 #ifndef BCN_PDF
 #define BCN_PDF 8    // fields in LDS: diagonals per block of the transport wave (two register sets: it runs PDF..2 PDF diagonals ahead;
                      // measured 4 / 6 / 8 / 12 / 16: 26.2 / 25.7 / 24.8 / 25.3 / 26.3 k cycles per timestep outside the solve)
@@ -95,11 +97,7 @@ struct FastGeom {
   // [3][R][64] elements behind everything else (fast_body)
   static constexpr size_t SCR = 3 * (size_t)R * 64;
   template <typename real> static constexpr bool offload() {
-#ifdef BCN_NO_OFFLOAD   // experiment switch
-    return false;
-#else
     return NW >= 3 && (R + 3) / 4 <= NW - 1 && (base_elems() + SCR) * sizeof(real) <= 160 * 1024;
-#endif
   }
   template <typename real> static constexpr size_t lds_bytes() {
     return (base_elems() + (offload<real>() ? SCR : 0)) * sizeof(real);
@@ -227,7 +225,6 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
   const int j = lane + 1;
   const bool active = lane < NY;
   const int cb = (1 - lane) * SY + j;
-#ifndef BCN_CHAIN_FLAT
   // Every field through a pointer of its OWN address space -- T: LDS (GF == 0) or the global scratch (the masked lanes' sink
   // then lies in the scratch's front pad); u, v: the global scratch with GF == 1, LDS otherwise.  As generic pointers of this
   // out-of-line function every access of the global scratch was a flat_load / flat_store, which count on BOTH wait counters
@@ -237,12 +234,6 @@ __device__ __attribute__((noinline)) void transport_chain(real* Tl, const real* 
   typedef typename std::conditional<GF == 1, __attribute__((address_space(1))) real, __attribute__((address_space(3))) real>::type ureal;
   treal* const Tb = (treal*)(Tl + cb);
   treal* const dummy_t = GF != 0 ? (treal*)(Tl - G::FRONTG) : (treal*)dummy;
-#else
-  typedef real treal;
-  typedef real ureal;
-  real* const Tb = Tl + cb;
-  real* const dummy_t = dummy;
-#endif
   const ureal* const Ug = (const ureal*)Ul;
   const ureal* const Vg = (const ureal*)Vl;
   auto ldu = [&](int t) -> real { const int x = cb + t * SY; return GF == 2 ? Ug[x < 0 ? 0 : (x >= G::SZ ? G::SZ - 1 : x)] : Ug[x]; };
@@ -318,25 +309,10 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   real* __restrict__ gp = A.p + off;
   real* __restrict__ gS = A.S + off;
   constexpr int XC = G::XC, XL = XC - 1;   // XL: slot of the strip's last column
-  // exchange buffer [2 buffers][NW][64 lanes][XC columns of the strip]: lane-major, so that a sweep publishes its XC exchanged
-  // columns with ONE wide store per lane and fetches the two columns facing it from each neighbour with ONE 64-bit load
-  // (was four 32-bit stores and four loads per double sweep: every LDS instruction next to the sweep's barrier costs 30-50
-  // cycles of issue)
-  typedef real rv4 __attribute__((ext_vector_type(4)));
-  typedef real rv2 __attribute__((ext_vector_type(2)));
-#ifndef BCN_OVF_FIRST
-#define BCN_OVF_FIRST 1   // (0: experiment -- the overflow test behind the pass test, as before round 4)
-#endif
-#ifndef BCN_XPACK
-#define BCN_XPACK 0   // 0: column-major exchange buffer, one 32-bit access per column; 1: lane-major, one 128-bit store and two 64-bit
-                      // loads per double sweep; 2: lane-major, 64-bit pairs.  Measured on the bench workload (round 4): 738 / 750 / 750
-                      // cycles per sweep -- here the four narrow stores drain behind the interior cells, the wide one does not
-                      // (the two-rows-per-lane kernel, with its single sweeps, gains 3.5 % from the packed form: ns2d_fast2_impl.h)
-#endif
-  auto exl = [&](int buf, int wave, int which) -> real& {
-    if (BCN_XPACK == 0) return exch[((buf * NW + wave) * XC + which) * 64 + lane];
-    return exch[((buf * NW + wave) * 64 + lane) * XC + which];
-  };
+  // exchange buffer [2 buffers][NW][XC columns of the strip][64 lanes]: column-major, one 32-bit (64-bit) access per column.
+  // (Measured in round 4 and dropped: lane-major with one 128-bit store and two 64-bit loads per double sweep -- 750 against 738
+  // cycles per sweep on the bench workload: the four narrow stores drain behind the interior cells, the wide one does not.)
+  auto exl = [&](int buf, int wave, int which) -> real& { return exch[((buf * NW + wave) * XC + which) * 64 + lane]; };
 
   // ---- load: HBM [j][i] -> LDS [i][j]; p -> registers --------------------------------------
   for (int c = tid; c < SX * SY; c += NT) {
@@ -533,14 +509,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         }                                                                                                       \
       }                                                                                                         \
     }
-#ifdef BCN_DBG_NOHELP   // timing experiment (same results): nothing runs beside the chain, every wave computes its own strip behind it
-    __syncthreads();
-    if (have_pred) BCN_OWN_PRED
-    if constexpr (false) {
-#else
     if (pred_own) BCN_OWN_PRED
     if constexpr (OFFLOAD) {
-#endif
       // strip 0 for wave 0, in chunks of four columns dealt to the helper waves (in an 8-wave workgroup wave 4 shares its
       // SIMD with wave 0: it comes last)
       if (have_pred && have_chain && w != 0) {
@@ -588,7 +558,6 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     BCN_PH(5)
     if (!have_pred) break;
     asm volatile("" : "+v"(j));   // keep hipcc from hoisting (and spilling) a whole timestep's LDS addresses out of the loop
-#ifndef BCN_DBG_NOHELP
     if (w == 0 && have_chain) {
       if constexpr (OFFLOAD) {
 #pragma unroll
@@ -597,7 +566,6 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         BCN_OWN_PRED
       }
     }
-#endif
 #undef BCN_OWN_PRED
     // ---- boundary conditions of T (rayleigh.py:180-202, the T part) on the transported field --------------
     // TREG (T in the global scratch, GF == 2): every thread loads its own row of T once (one coalesced load per column, all
@@ -718,7 +686,11 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     int itp;
     real phA[R], phB[R];
     bool finalB;
-    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)A.tol * 1.003f);
+    // tolL: what a LANDING evaluation -- the first one behind skipped sweeps -- must exceed for the skip to be verified.  Plan 3:
+    // BCN_CONV_GUARD * tol, which PROVES that no skipped sweep passed (bcn_common.h); the plan aims its landings above it.
+    // Plan 2: tol itself (only a landing that passes is noticed: the unguarded rule of round 2).
+    const real tolL = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
+    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)tolL * 1.003f);
     constexpr int JMAX = 256;
 #ifdef BCN_DBG_NCHK
     int nchk = 0;
@@ -763,31 +735,13 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       DST[R - 1] = pl;                                                                       \
       BCN_PUBLISH(DST)
 #define BCN_PUBLISH(DST)                                                                     \
-      if constexpr (BCN_XPACK == 0) {                                                        \
-        exl(xb, w, 0) = DST[0];                                                              \
-        exl(xb, w, XL) = DST[R - 1];                                                         \
-        if constexpr (XC == 4) { exl(xb, w, 1) = DST[1]; exl(xb, w, 2) = DST[R - 2]; }       \
-      } else if constexpr (XC == 4 && BCN_XPACK == 1) {                                      \
-        const rv4 pv = {DST[0], DST[1], DST[R - 2], DST[R - 1]};                             \
-        *reinterpret_cast<rv4*>(&exl(xb, w, 0)) = pv;                                        \
-      } else if constexpr (XC == 4) {                                                        \
-        const rv2 pw = {DST[0], DST[1]}, pe = {DST[R - 2], DST[R - 1]};                      \
-        *reinterpret_cast<rv2*>(&exl(xb, w, 0)) = pw;                                        \
-        *reinterpret_cast<rv2*>(&exl(xb, w, 2)) = pe;                                        \
-      } else {                                                                               \
-        const rv2 pv = {DST[0], DST[R - 1]};                                                 \
-        *reinterpret_cast<rv2*>(&exl(xb, w, 0)) = pv;                                        \
-      }
+      exl(xb, w, 0) = DST[0];                                                                \
+      exl(xb, w, XL) = DST[R - 1];                                                           \
+      if constexpr (XC == 4) { exl(xb, w, 1) = DST[1]; exl(xb, w, 2) = DST[R - 2]; }
 #define BCN_HALO_READS                                                                       \
-      if constexpr (XC == 4 && BCN_XPACK != 0) {                                             \
-        const rv2 hw = *reinterpret_cast<const rv2*>(&exl(xb, wm, 2));                       \
-        const rv2 he = *reinterpret_cast<const rv2*>(&exl(xb, wp, 0));                       \
-        hW2r = hw.x; hW1r = hw.y; hE1r = he.x; hE2r = he.y;                                  \
-      } else {                                                                               \
-        hW1r = exl(xb, wm, XL);                                                              \
-        hE1r = exl(xb, wp, 0);                                                               \
-        if constexpr (XC == 4) { hW2r = exl(xb, wm, 2); hE2r = exl(xb, wp, 1); }             \
-      }                                                                                      \
+      hW1r = exl(xb, wm, XL);                                                                \
+      hE1r = exl(xb, wp, 0);                                                                 \
+      if constexpr (XC == 4) { hW2r = exl(xb, wm, 2); hE2r = exl(xb, wp, 1); }               \
       xb ^= 1;
 #define BCN_SWEEP_END                                                                        \
       __syncthreads();                                                                       \
@@ -852,14 +806,15 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       /* behind the speculative jump the proven plan also needs the unweighted norm above its threshold */ \
       const bool amb = SPEC && skip_left == -2 && plan == 1 && !(read_lane(esum, 31) > A.tol * real(1.02)); \
       /* the reference tests the sweep count FIRST (rayleigh.py:451-454): sweep itmax + 1 overflows even if it passes */ \
-      if (BCN_OVF_FIRST && itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; if (SPEC) skip_left = 0; break; } \
-      if (!(err > A.tol) || amb) {                                                           \
+      if (itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; if (SPEC) skip_left = 0; break; } \
+      /* a landing (the sweep before this one was not evaluated) that does not clear tolL leaves the skipped sweeps unverified */ \
+      const bool unv = plan >= 2 && !A.verify_conv && itp >= 2 && k_prev != itp - 2 && !(err > tolL); \
+      if (!(err > A.tol) || amb || unv) {                                                    \
         if (skip_left > 0) status |= BCN_ST_PLAN;                                            \
         if (SPEC) skip_left = skip_left == -2 ? -1 : 0;                                      \
         finalB = DST_IS_B; break;                                                            \
       }                                                                                      \
       if (SPEC) skip_left = skip_left < 0 ? 0 : skip_left;                                   \
-      if (!BCN_OVF_FIRST && itp > A.itmax) { status |= BCN_ST_ITMAX; finalB = DST_IS_B; break; } \
       n = 0;                                                                                 \
       if (skip_left > 0) {                                                                   \
         skip_left--;                                                                         \
@@ -942,7 +897,10 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const bool pass1 = ov1 || !(err1 > A.tol), pass2 = ov2 || !(err2 > A.tol);             \
       /* behind the speculative jump the proven plan also needs the unweighted norm above its threshold */ \
       const bool amb = SPEC && skip_left == -2 && plan == 1 && !(read_lane(esum, 47) > A.tol * real(1.02)); \
-      if (pass1 || pass2 || amb) {                                                           \
+      /* the pair directly follows skipped sweeps (or the speculative opening) and its first sweep does not clear tolL: \
+         the skipped sweeps are not verified -- plan 3 repeats the solve, plan 2 notices it only when that sweep passes */ \
+      const bool unv = plan >= 2 && !A.verify_conv && itp0 > 0 && k_prev != itp0 && !(err1 > tolL); \
+      if (pass1 || pass2 || amb || unv) {                                                    \
         const bool ovf = ov1 || (ov2 && (err1 > A.tol));                                     \
         if (ovf) status |= BCN_ST_ITMAX;                                                     \
         if (!ovf && skip_left > (pass1 ? 0 : 1)) status |= BCN_ST_PLAN;   /* verify_conv: a sweep the plan skips passes */ \
@@ -952,7 +910,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         /* the first sweep was the last one: the west halo of ITS result is the neighbour's edge column as recomputed here */ \
         hW1r = pass1 ? yw : hW1r;                                                            \
         /* a stop the plan did not foresee: the passing sweep directly follows skipped ones */ \
-        late_stop = pass1 && !ovf && itp0 > 0 && k_prev != itp0;                             \
+        late_stop = unv && !ovf;                                                             \
         break;                                                                               \
       }                                                                                      \
       if (SPEC) skip_left = skip_left < 0 ? 0 : skip_left;                                   \
@@ -1196,15 +1154,9 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
   else fast_body<real, NX, NY, R, R, KIND, EQ, GF>(A, w, b, it_begin, it_end, first_chunk, last_chunk, smem);
 }
 
-#ifdef BCN_JIT_WPE   // experiment: cap the registers so that BCN_JIT_WPE waves fit a SIMD (two workgroups per CU)
-#define BCN_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(BCN_JIT_WPE, BCN_JIT_WPE)))
-#else
-#define BCN_KERNEL_ATTR
-#endif
-
 // plain launch: one workgroup per replica, timesteps [A.it_begin, A.it_end)
 template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__global__ BCN_KERNEL_ATTR __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_step(NS2DArgs<real> A) {
+__global__ __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_step(NS2DArgs<real> A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
   if (A.mask && !A.mask[b]) return;
@@ -1213,7 +1165,7 @@ __global__ BCN_KERNEL_ATTR __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void
 
 // ---- ticketed chunk scheduler (ns2d_sched.h) ---------------------------------------------------
 template <typename real, int NX, int NY, int R, int KIND, bool EQ, int GF>
-__global__ BCN_KERNEL_ATTR __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
+__global__ __launch_bounds__((FastGeom<NX, NY, R, GF>::NT)) void ns2d_fast_sched(NS2DArgs<real> A, SchedCtl* ctl, int batch, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // two words behind fast_body's scalars (no static __shared__ in front of the dynamic region)
   unsigned int* s_words = reinterpret_cast<unsigned int*>(reinterpret_cast<real*>(smem) +
@@ -1259,7 +1211,6 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
   }
   NS2DArgs<real> c = a;
   if (!c.sweeps) c.sweeps = c.sweeps_int;
-  if (const char* e = getenv("BCN_VERIFY_CONV")) c.verify_conv = atoi(e);
   const SchedParams sp = ns2d_sched_params(a);
   const int mode = sp.mode, sched_grid = sp.grid, SQ = sp.q;
   if (mode == 2 && batch > sched_grid && a.ndt_act >= 2 * SQ && a.sched_ctl) {
@@ -1269,12 +1220,12 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
       BCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     int nchunk = 0;
-    ns2d_sched_chunks(a.ndt_act, SQ, &c.sched_nbig, &nchunk);
+    ns2d_sched_chunks(a.ndt_act, SQ, (a.host ? a.host->sched_tail : 0), &c.sched_nbig, &nchunk);
     c.sched_q = SQ; c.order = nullptr; c.first_chunk = 1; c.last_chunk = 1; c.it_begin = 0; c.it_end = a.ndt_act;
     BCN_HIP(hipMemsetAsync(a.sched_ctl, 0, a.sched_bytes, s));
     hipLaunchKernelGGL(ks, dim3(sched_grid), dim3(G::NT), lds, s, c, static_cast<SchedCtl*>(a.sched_ctl), batch, nchunk);
     BCN_HIP(hipGetLastError());
-    if (a.launched) *a.launched = "ns2d_fast_sched";
+    if (a.host) a.host->launched = "ns2d_fast_sched";
     return BCN_OK;
   }
   // split only when replicas outnumber the CUs (otherwise every replica starts at once and
@@ -1295,7 +1246,7 @@ int launch_fast_eq(const NS2DArgs<real>& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(batch), dim3(G::NT), lds, s, c);
   }
   BCN_HIP(hipGetLastError());
-  if (a.launched) *a.launched = "ns2d_fast_step";
+  if (a.host) a.host->launched = "ns2d_fast_step";
   return BCN_OK;
 }
 

@@ -430,7 +430,7 @@ int launch_step(const NS2DArgs<real>& a_in, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(batch), dim3(NT), lds, s, a);
   }
   BCN_HIP(hipGetLastError());
-  if (a.launched) *a.launched = "ns2d_generic_step";
+  if (a.host) a.host->launched = "ns2d_generic_step";
   return BCN_OK;
 }
 
@@ -444,9 +444,8 @@ size_t ns2d_generic_lds_bytes(int ncell, size_t esz) {
 
 template <typename real>
 int ns2d_launch_generic(const NS2DArgs<real>& a, int batch, hipStream_t s) {
-  // 16 waves when there is enough work per replica to feed them, else 4 (BCN_GENERIC_NT overrides: experiments)
-  static int force_nt = -1;
-  if (force_nt < 0) { const char* e = getenv("BCN_GENERIC_NT"); force_nt = e ? atoi(e) : 0; }
+  // 16 waves when there is enough work per replica to feed them, else 4 (bcn_set_option "generic_threads": 256 / 1024)
+  const int force_nt = a.host ? a.host->generic_nt : 0;
   if (force_nt == 1024 || (force_nt == 0 && a.nx * a.ny >= 4096)) return launch_step<real, 1024>(a, batch, s);
   return launch_step<real, 256>(a, batch, s);
 }

@@ -92,16 +92,14 @@ inline bool ns2d_first_on_device(unsigned long long& seen) {
   return true;
 }
 
-// host side: BCN_SCHED = 0 plain launch, 1 two-launch LPT split (ns2d_fast only), 2 ticketed chunks
-// (default); BCN_SCHED_GRID persistent workgroups (default: one per CU of the handle's device); BCN_SCHED_Q
-// timesteps per chunk.  The environment gives the process-wide defaults; bcn_set_sched() overrides them per
-// handle (NS2DArgs::sched_mode / sched_grid / sched_q_user, -1 / 0 / 0 = default).
+// host side, per handle (bcn_set_sched -> NS2DArgs::sched_mode / sched_grid / sched_q_user / lpt_min_batch; -1 / 0 = default):
+// mode 0 plain launch, 1 two-launch LPT split (ns2d_fast only), 2 ticketed chunks (default); grid = persistent workgroups
+// (default: one per CU of the handle's device); q = timesteps per chunk.  No environment variable changes any of it.
 // chunks of one step: nbig long ones (2 q timesteps) followed by short ones (q; the last takes the remainder), the short
-// tail covering at least the last `tail` * q timesteps.  BCN_SCHED_TAIL overrides tail (default 6); a tail >= ndt / q
-// gives uniform chunks.
-inline void ns2d_sched_chunks(int ndt, int q, int* nbig, int* nchunk) {
-  static int tail = -1;
-  if (tail < 0) { const char* e = getenv("BCN_SCHED_TAIL"); tail = e ? atoi(e) : 6; }
+// tail covering at least the last `tail` * q timesteps (bcn_set_option "sched_tail", default 6; a tail >= ndt / q gives
+// uniform chunks).
+inline void ns2d_sched_chunks(int ndt, int q, int tail_user, int* nbig, int* nchunk) {
+  const int tail = tail_user > 0 ? tail_user : 6;
   int nb = (ndt - tail * q) / (2 * q);
   if (nb < 0) nb = 0;
   int rem = ndt - nb * 2 * q;
@@ -128,24 +126,13 @@ inline int ns2d_cu_count() {   // of the current device (one handle per device; 
 }
 template <typename real>
 inline SchedParams ns2d_sched_params(const NS2DArgs<real>& a) {
-  static int env_mode = -2, env_grid = 0, env_q = 0, env_lpt = 0;
-  if (env_mode == -2) {
-    const char* e = getenv("BCN_SCHED");
-    const char* g = getenv("BCN_SCHED_GRID");
-    const char* q = getenv("BCN_SCHED_Q");
-    const char* l = getenv("BCN_LPT_MIN_BATCH");
-    env_grid = g ? atoi(g) : 0;
-    env_q = (q && atoi(q) > 0) ? atoi(q) : 0;
-    env_lpt = l ? atoi(l) : 0;
-    env_mode = e ? atoi(e) : 2;
-  }
   SchedParams p;
-  p.mode = a.sched_mode >= 0 ? a.sched_mode : env_mode;
+  p.mode = a.sched_mode >= 0 ? a.sched_mode : 2;
   const int ncu = ns2d_cu_count();
-  p.grid = a.sched_grid > 0 ? a.sched_grid : (env_grid > 0 ? env_grid : ncu);
-  const int q = a.sched_q_user > 0 ? a.sched_q_user : env_q;
+  p.grid = a.sched_grid > 0 ? a.sched_grid : ncu;
+  const int q = a.sched_q_user;
   p.q_set = q > 0;
   p.q = q > 0 ? q : 10;
-  p.lpt_min_batch = a.lpt_min_batch > 0 ? a.lpt_min_batch : (env_lpt > 0 ? env_lpt : ncu + 1);
+  p.lpt_min_batch = a.lpt_min_batch > 0 ? a.lpt_min_batch : ncu + 1;
   return p;
 }

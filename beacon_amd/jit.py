@@ -57,7 +57,7 @@ def _choose4(nx, ny, f64):
         return None
     rpl = -(-ny // 64)
     for nwmax, words in ((16, 28), (8, 60)):
-        if (f64 and nwmax > 8) or nwmax > int(os.environ.get("BEACON_JIT_F4_NWMAX", "16")):   # (the variable: experiments)
+        if f64 and nwmax > 8:
             continue
         r = -(-nx // nwmax)
         nw = -(-nx // r)
@@ -91,23 +91,23 @@ def choose(nx, ny, f64, kind):
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
                 continue
             # float64: strips of equal width only (one instantiation of the body), and at most 16 columns per lane.  The
-            # two-body float64 kernel of 110x64 (strips of 14 and 12 columns, u, v in LDS, T in the global scratch) stopped
-            # converging in its third timestep after a semantically neutral reordering of two tests in the Jacobi loop
-            # (round 4; column 99, the narrow strip's first one; root cause not found): such grids take the hybrid kernel
-            # of ns2d_fast4_impl.h (below) instead
-            if f64 and (rl != r or r > 16) and os.environ.get("BEACON_JIT_F64_TWOBODY") != "1":   # (the switch: experiments)
+            # two-body float64 kernel of 110x64 (strips of 14 and 12 columns, u, v in LDS, T in the global scratch, strip 0
+            # handed to the helper waves) computed ONE wrong word per timestep under a neutral source change -- lane 0 of the
+            # column where the two bodies meet, in every replica, at every batch size, whatever the data; 6 of 21 unrelated
+            # code-generation flags make the same source exact (code generation at the register limit,
+            # not a race).  Such grids take the hybrid kernel of ns2d_fast4_impl.h (below); every plugin, of whatever family,
+            # is compared with the generic kernel before its first use (verify()).
+            if f64 and (rl != r or r > 16):
                 continue
             for gf in ((0,) if not f64 else (2, 1)):
                 if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
     elif 64 < ny <= 128:
         # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); rayleigh and mixing alike
-        # (BEACON_JIT_NW: experiments -- only this wave count)
-        only = int(os.environ.get("BEACON_JIT_NW", "0"))
-        for nw, rmax in (((only, 26),) if only else ((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
+        for nw, rmax in (((8, 13), (7, 13), (6, 13), (5, 13), (4, 13)) if f64 else ((8, 16), (12, 10), (16, 7), (7, 16), (6, 20), (5, 24), (4, 26))):
             r = -(-nx // nw)
             rl = nx - (nw - 1) * r
-            if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx or (only and nw != only):
+            if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
                 continue
             exch = 2 * nw * 4 * 64 + 160
             lds = (exch + 2 * r * nw * 64) * esz if f64 else (exch + 3 * (nx + 2) * (ny + 2)) * esz
@@ -233,11 +233,9 @@ def build_plugin(nx, ny, f64, kind, verbose=False, extra_defs=None):
     if m is None or os.environ.get("BEACON_JIT", "1") == "0":
         return None
     defs = {"BCN_JIT_ROWS": m["rows"], "BCN_JIT_REAL": "double" if f64 else "float", "BCN_JIT_NX": nx, "BCN_JIT_NY": ny,
-            "BCN_JIT_R": m["R"], "BCN_JIT_KIND": kind, "BCN_JIT_GF": int(os.environ.get("BEACON_JIT_GF", m["gf"]))}
+            "BCN_JIT_R": m["R"], "BCN_JIT_KIND": kind, "BCN_JIT_GF": m["gf"]}
     if m["rows"] == 4:
         defs["BCN_JIT_RPL"] = m["rpl"]
-    if os.environ.get("BEACON_JIT_WPE"):              # experiment: waves per SIMD the register allocation must allow
-        defs["BCN_JIT_WPE"] = int(os.environ["BEACON_JIT_WPE"])
     for d in os.environ.get("BEACON_JIT_DEFS", "").split():   # experiments: extra -D flags (scripts/tall_base.py)
         defs[d.partition("=")[0]] = d.partition("=")[2] or "1"
     defs.update(extra_defs or {})

@@ -50,6 +50,17 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_OPS = ("rayleigh_reset", "rayleigh_step", "mixing_reset", "mixing_step", "burgers_reset", "burgers_step", "shkadov_reset",
+        "shkadov_step", "sloshing_reset", "sloshing_step")
+
+
+def _op_table():
+    """{name: torch.ops.beacon.<name>.default} of the torch extension (beacon_amd/torch_ext.py), or None without it."""
+    from . import torch_ext
+    ops = torch_ext.load()
+    return None if ops is None else {n: getattr(ops, n).default for n in _OPS}
+
+
 class VecEnv(object):
     """Common machinery.  Subclasses set self.cfg and implement _create/_reset/_step."""
 
@@ -61,6 +72,9 @@ class VecEnv(object):
         if not torch.cuda.is_available():
             raise RuntimeError("beacon_amd needs a ROCm GPU: the solver path is HIP-only (no CPU fallback)")
         self.lib = _lib.load()
+        # the torch.library ops over the same C ABI (beacon_amd/torch_ext.py): one dispatcher call per reset() / step();
+        # None (no compiler and no prebuilt extension, or BEACON_TORCH_EXT=0): the ctypes binding below
+        self._ops = _op_table()
         self.batch = int(batch)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -69,6 +83,7 @@ class VecEnv(object):
         self.device = torch.device("cuda", self.dev_index)
         self.tdtype, self.cdtype = _DT[dtype]
         self.h = C.c_void_p()
+        self._mask = None
         self._create()
         self.obs_dim = self.lib.bcn_n_obs(self.h)       # observation length per replica
         self.n_actions = self.lib.bcn_n_act(self.h)
@@ -128,6 +143,9 @@ class VecEnv(object):
         """actions / noise / init fields -> contiguous device tensor of the env dtype."""
         if x is None:
             return None
+        if (torch.is_tensor(x) and x.dtype == self.tdtype and x.device == self.device and tuple(x.shape) == tuple(shape)
+                and x.is_contiguous()):
+            return x                      # what a trainer passes every step: nothing to convert
         if not torch.is_tensor(x):
             x = torch.as_tensor(np.asarray(x, dtype=np.float64))
         x = x.to(device=self.device, dtype=self.tdtype).reshape(shape).contiguous()
@@ -194,6 +212,12 @@ class VecEnv(object):
             _lib.check(self.lib.bcn_set_fast_plugin(self.h, p.fn, p.scratch))
             self._plugin = p
 
+    def use_torch_ops(self, on=True):
+        """Switch this env between the two bindings of the C ABI: the torch.library ops (default when the extension is built)
+        and ctypes.  Returns whether the ops are in use.  Results do not depend on it (tests/test_gpu_parity.py)."""
+        self._ops = _op_table() if on else None
+        return self._ops is not None
+
     def set_option(self, name, value):
         """Solver options by name (include/beacon_hip.h: bcn_set_option), e.g. ("conv_plan", 0)."""
         _lib.check(self.lib.bcn_set_option(self.h, name.encode(), int(value)))
@@ -256,13 +280,17 @@ class VecEnv(object):
         return self.obs, None
 
     def step(self, actions=None, noise=None, mask=None):
-        self._next_outputs(carry=mask is not None)
-        self._apply_mask(mask)
-        try:
-            self._step(actions, noise)
-        finally:
-            if mask is not None:
-                self._apply_mask(None)
+        if self._rotate:
+            self._next_outputs(carry=mask is not None)
+        if mask is None and getattr(self, "_mask", None) is None:
+            self._step(actions, noise)            # the common case: no mask now, none set -- nothing to tell the library
+        else:
+            self._apply_mask(mask)
+            try:
+                self._step(actions, noise)
+            finally:
+                if mask is not None:
+                    self._apply_mask(None)
         return self.obs, self.rwd, self.done, self.trunc, None
 
     def capture(self, actions, noise=None, n_steps=None, keep_steps=True):
@@ -436,11 +464,16 @@ class VecRayleigh(VecEnv):
         return np.ascontiguousarray(st[0].double().cpu().numpy().transpose(0, 2, 1))
 
     def _reset(self):
+        if self._ops is not None:
+            return self._ops["rayleigh_reset"](self.h.value, self._init_dev, self.obs)
         _lib.check(self.lib.bcn_rayleigh_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))
 
     def _step(self, actions, noise=None):
         a = self._real(actions, (self.batch, self.n_sgts))
         self._keep = a
+        if self._ops is not None:
+            return self._ops["rayleigh_step"](self.h.value, a, self.actions_norm, self.obs, self.rwd, self.done, self.trunc,
+                                              self.status, self.sweeps)
         _lib.check(self.lib.bcn_rayleigh_step(self.h, _ptr(a), _ptr(self.actions_norm), _ptr(self.obs),
                                               _ptr(self.rwd), _ptr(self.done), _ptr(self.trunc),
                                               _ptr(self.status), _ptr(self.sweeps), self._stream()))
@@ -507,6 +540,8 @@ class VecMixing(VecEnv):
         return (4, self.ny + 2, self.nx + 2)
 
     def _reset(self):
+        if self._ops is not None:
+            return self._ops["mixing_reset"](self.h.value, self.obs)
         _lib.check(self.lib.bcn_mixing_reset(self.h, _ptr(self.obs), self._stream()))
 
     def _step(self, actions, noise=None):
@@ -516,6 +551,8 @@ class VecMixing(VecEnv):
                 actions = torch.as_tensor(np.asarray(actions, dtype=np.int64))
             a = actions.to(device=self.device, dtype=torch.int32).reshape(self.batch).contiguous()
         self._keep = a
+        if self._ops is not None:
+            return self._ops["mixing_step"](self.h.value, a, self.obs, self.rwd, self.done, self.trunc, self.status, self.sweeps)
         _lib.check(self.lib.bcn_mixing_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.rwd), _ptr(self.done),
                                             _ptr(self.trunc), _ptr(self.status), _ptr(self.sweeps),
                                             self._stream()))
@@ -570,12 +607,16 @@ class VecBurgers(VecEnv):
         return (2.0 * r - 1.0) * self.sigma
 
     def _reset(self):
+        if self._ops is not None:
+            return self._ops["burgers_reset"](self.h.value, self.obs)
         _lib.check(self.lib.bcn_burgers_reset(self.h, _ptr(self.obs), self._stream()))
 
     def _step(self, actions, noise=None):
         a = self._real(actions, (self.batch,))
         nz = None if noise is None else self._real(noise, (self.batch,))     # None: drawn inside the kernel
         self._keep = (a, nz)
+        if self._ops is not None:
+            return self._ops["burgers_step"](self.h.value, a, nz, self.obs, self.rwd, self.done, self.trunc, self.status)
         _lib.check(self.lib.bcn_burgers_step(self.h, _ptr(a), _ptr(nz), _ptr(self.obs), _ptr(self.rwd),
                                              _ptr(self.done), _ptr(self.trunc), _ptr(self.status),
                                              self._stream()))
@@ -659,12 +700,16 @@ class VecShkadov(VecEnv):
         return self.obs, None
 
     def _reset(self):
+        if self._ops is not None:
+            return self._ops["shkadov_reset"](self.h.value, self._init_dev, self.obs)
         _lib.check(self.lib.bcn_shkadov_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))
 
     def _step(self, actions, noise=None):
         a = self._real(actions, (self.batch, self.n_jets))
         nz = None if noise is None else self._real(noise, (self.batch, self.ndt_act))   # None: drawn inside the kernel
         self._keep = (a, nz)
+        if self._ops is not None:
+            return self._ops["shkadov_step"](self.h.value, a, nz, self.obs, self.rwd, self.done, self.trunc, self.status)
         _lib.check(self.lib.bcn_shkadov_step(self.h, _ptr(a), _ptr(nz), _ptr(self.obs), _ptr(self.rwd),
                                              _ptr(self.done), _ptr(self.trunc), _ptr(self.status),
                                              self._stream()))
@@ -716,10 +761,14 @@ class VecSloshing(VecEnv):
         return 0.5 * (np.cos(np.pi * t) + 3.0 * np.cos(4.0 * np.pi * t))
 
     def _reset(self):
+        if self._ops is not None:
+            return self._ops["sloshing_reset"](self.h.value, self._init_dev, self.obs)
         _lib.check(self.lib.bcn_sloshing_reset(self.h, _ptr(self._init_dev), _ptr(self.obs), self._stream()))
 
     def _step(self, actions, noise=None):
         a = self._real(actions, (self.batch,))
         self._keep = a
+        if self._ops is not None:
+            return self._ops["sloshing_step"](self.h.value, a, self.obs, self.rwd, self.done, self.trunc, self.status)
         _lib.check(self.lib.bcn_sloshing_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.rwd), _ptr(self.done),
                                               _ptr(self.trunc), _ptr(self.status), self._stream()))

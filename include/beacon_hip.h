@@ -54,7 +54,7 @@ enum { BCN_F32 = 0, BCN_F64 = 1 };
 enum { BCN_OK = 0, BCN_ERR_ARG = 1, BCN_ERR_HIP = 2, BCN_ERR_UNSUPPORTED = 3 };
 /* per-replica status word written by *_step */
 enum { BCN_ST_OK = 0, BCN_ST_ITMAX = 1, BCN_ST_BLOWUP = 2,
-       BCN_ST_PLAN = 4 /* diagnostic (BCN_VERIFY_CONV=1): a Jacobi sweep the residual-evaluation plan skips passed the test */ };
+       BCN_ST_PLAN = 4 /* diagnostic (bcn_set_option "verify_conv"): a Jacobi sweep the residual-evaluation plan skips passed the test */ };
 /* env kinds (bcn_env_kind) */
 enum { BCN_RAYLEIGH = 0, BCN_MIXING = 1, BCN_BURGERS = 2, BCN_SHKADOV = 3, BCN_SLOSHING = 4 };
 
@@ -198,15 +198,14 @@ BCN_API int bcn_set_stp(bcn_env_t h, const int32_t* buf_host, void* stream);
 BCN_API int bcn_set_variant(bcn_env_t h, int variant);
 /* Measurement aid (no reference counterpart), uint64[B][4] on the host, per replica, of the last *_step (all chunks):
  *   [0] shader-clock cycles inside the Jacobi loop (rayleigh.py:419-454 / mixing.py:428-463), [1] in the whole replica,
- *   [2] "late stops": solves whose passing evaluation of the residual directly followed sweeps that the extrapolating
- *       plan (conv_plan 2 / 3) had skipped -- the plan did not foresee the stop, so an earlier sweep may have passed too,
- *   [3] timesteps (rayleigh) / solves (two-rows-per-lane and tall-grid kernels) that were repeated: a speculative jump that went too
- *       far, or conv_plan 3 repeating a late stop under the proven plan.
+ *   [2] solves whose LANDING -- the first evaluation of the residual behind sweeps the extrapolating plan (conv_plan 2 / 3) had
+ *       skipped -- did not verify the skip: under plan 3 the residual was not above BCN_CONV_GUARD * tol there (so a skipped
+ *       sweep may have passed the test); under plan 2 the landing itself passed,
+ *   [3] timesteps (rayleigh) / solves (two-rows-per-lane and tall-grid kernels) that were repeated: a speculative opening whose
+ *       landing did not verify it, or conv_plan 3 repeating an unverified solve under the proven plan.
  * Zeros for kernels that do not count (generic 2D kernel, 1D envs).
- * NOTE on [2]/[3] under conv_plan 3 with the speculative jump (spec_start > 0): the jump's FIRST evaluation failing is taken as
- * proof that no earlier sweep passed, which rests on the observed -- not proven -- monotone decay of the weighted norm; such a
- * miss would show in neither counter, so zeros in [2] do not by themselves certify that every stop sweep is the reference's
- * ("verify_conv" checks exactly that, and conv_plan 1 / spec_start 0 are the proven settings).
+ * Under conv_plan 3 every stop sweep is the reference's BY PROOF (see "conv_plan"): zeros in [2] mean that no solve needed the
+ * repeat, not that something went unnoticed.
  * buf_host must hold batch * BCN_COUNTER_WORDS words; bcn_get_counters_n writes `words_per_replica` words per replica instead
  * (the first min(words, BCN_COUNTER_WORDS) counters, zeros beyond) for callers built against another header. */
 BCN_API int bcn_get_counters(bcn_env_t h, uint64_t* buf_host, void* stream);
@@ -229,27 +228,39 @@ BCN_API int bcn_set_fast_plugin(bcn_env_t h, void* launch_fn, size_t scratch_ele
  * replica 0 (sharded batches).  Resets the replicas' draw counters.  BCN_ERR_ARG for envs without inlet noise. */
 BCN_API int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t replica_offset);
 /* Solver options of the 2D envs (no reference counterpart), by name:
- *   "conv_plan"   which Jacobi sweeps evaluate the residual sum((phi - phin)^2) of rayleigh.py:448-449 / mixing.py:457-458
- *                 in the register-resident kernels: 0 = every sweep, as the reference does; 1 = every sweep that can pass
- *                 the test according to a PROVEN lower bound of the norm (exactly the reference's stop sweep; default for
- *                 BCN_F64); 2 = additionally extrapolating the decay of the reference's norm, which is observed -- not
- *                 proven -- never to speed up: should it ever, the solve stops a few sweeps after the reference's stop
- *                 sweep (inside the float32 tolerance), and bcn_get_counters reports it as a late stop; 3 = plan 2, but a
- *                 late stop is repeated under plan 1 (default for BCN_F32; see ns2d_fast_impl.h)
- *   "plan_overshoot" 0..64, TEST HOOK: lengthens every skip of plans 2 / 3 by that many sweeps, so that late stops occur
+ *   "conv_plan"   which Jacobi sweeps evaluate the residual err = sum((phi - phin)^2) of rayleigh.py:448-449 / mixing.py:457-458
+ *                 in the register-resident kernels.  Every plan returns the reference's stop sweep -- the FIRST sweep with
+ *                 err <= tol -- and differs only in how it knows that the sweeps it does not evaluate could not pass:
+ *                 0 = every sweep evaluated, as the reference does;
+ *                 1 = sweeps skipped while a PROVEN lower bound of err stays above tol: the increments obey d' = J d with J
+ *                     symmetric, so the plain norm |d|^2 <= err is log-convex in the sweep count and its measured decay bounds
+ *                     every later one (the default of BCN_F64 until round 5; what plan 3 repeats an unverified solve under);
+ *                 3 = the decay of err itself extrapolated, landing where it is still expected above 1.035 tol, and every
+ *                     landing -- the first evaluation behind skipped sweeps, the speculative opening's included -- VERIFIED:
+ *                     err can grow from a sweep to a later one by at most max_m || W^1/2 J^m W^-1/2 ||^2 = 1.030 (W = I + G:
+ *                     the ghost copies the reference's sum counts; scripts/weighted_norm_bound.py, every grid of the
+ *                     reference's constructor space), so had a skipped sweep passed, the landing would find err <= 1.030 tol;
+ *                     a landing above BCN_CONV_GUARD = 1.035 tol therefore proves that none did, and a landing below it is
+ *                     counted ([2]) and the solve repeated under plan 1 (the default of both precisions; grids with a side below 48
+ *                     cells, where the bound is larger, take plans 0 / 1 only);
+ *                 2 = plan 3's extrapolation WITHOUT the verification (round 2's rule: it notices a landing only when the
+ *                     landing itself passes, and then only counts it): kept for measurements, never a default
+ *   "plan_overshoot" 0..64, TEST HOOK: lengthens every skip of plans 2 / 3 by that many sweeps, so that landings fall behind
+ *                 the stop sweep (tests/test_gpu_parity.py: the adversarial right-hand side)
  *   "verify_conv" 1 = evaluate every sweep anyway and raise BCN_ST_PLAN if a sweep the plan skips passes the test
  *   "spec_start"  0..16: open a solve with unevaluated double sweeps up to spec_start/8 of the previous timestep's sweep
- *                 count and evaluate the residual there for the first time; if that evaluation passes, the solve is
- *                 repeated without the guess.
- *                 Plans 2 / 3 only: the jump relies on the same observed monotonicity of the reference's norm as those
- *                 plans themselves (the proven plan 1 would have to find the unweighted norm above the tolerance where
- *                 it lands, which it almost never is).  BCN_F32 rayleigh only (default 7); ignored by BCN_F64 handles,
- *                 off for mixing
+ *                 count; the landing behind them is verified like any other (plan 3: above 1.035 tol, else the solve is
+ *                 repeated without the guess).  BCN_F32 rayleigh only (default 6); ignored by BCN_F64 handles, off for mixing
+ *   "sched_tail"  short chunks that end a step of the ticket scheduler (0 = default 6; see bcn_set_sched)
+ *   "generic_threads" 256 / 1024: workgroup size of the generic 2D kernel (0 = chosen by grid size)
+ *   "cells_per_thread" (1D envs) 1, 2, 4, 8 cells per thread (0 = chosen from grid and batch); "one_wave" (1D envs) 0 / 1:
+ *                 grids up to 512 cells as one wave per replica with DPP halos (default 1)
+ * No environment variable changes any of these (round 5: the library reads none).
  * Returns BCN_ERR_ARG for unknown names. */
 BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference
  * counterpart: the reference steps one env per process, rayleigh.py:138-157).  mode: -1 = default
- * (environment BCN_SCHED, else 2), 0 = one workgroup per replica in one launch, 1 = two launches with the
+ * (2), 0 = one workgroup per replica in one launch, 1 = two launches with the
  * replicas re-ordered longest-first, 2 = persistent workgroups drawing (chunk of q timesteps, replica)
  * tickets; grid = persistent workgroups (0 = one per CU); q = timesteps per chunk (0 = kernel default);
  * lpt_min_batch = smallest batch that mode 1 splits (0 = CUs + 1).  Results do not depend on the mode. */

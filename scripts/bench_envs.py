@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--no-cpu", action="store_true")
 ap.add_argument("--only", default="")
+ap.add_argument("--opt", action="append", default=[], help="name=value for bcn_set_option on every env (e.g. cells_per_thread=4)")
 args = ap.parse_args()
 dev = "cuda:0"
 
@@ -48,6 +49,8 @@ rng = np.random.default_rng(7)
 if not args.only or "burgers" in args.only:
     B = 1024
     env = V.VecBurgers(B, dev, "f32", nx=512)
+    for o in args.opt:
+        env.set_option(o.split("=")[0], int(o.split("=")[1]))
     env.reset()
     a = torch.as_tensor(rng.uniform(-1, 1, (K + W, B)), dtype=torch.float32, device=dev)
     nz = torch.as_tensor(rng.uniform(-0.1, 0.1, (K + W, B)), dtype=torch.float32, device=dev)
@@ -63,6 +66,8 @@ if not args.only or "burgers" in args.only:
 if not args.only or "shkadov" in args.only:
     B = 1024
     env = V.VecShkadov(B, dev, "f32", None, L0=699.2, n_jets=10)
+    for o in args.opt:
+        env.set_option(o.split("=")[0], int(o.split("=")[1]))
     env.reset()
     # from a developed film (shkadov/init.py: 4000 uncontrolled action steps under inlet noise), as bench.py's line
     env.warmup(env.n_warmup_ref, torch.zeros((B, 10), dtype=torch.float32, device=dev))
@@ -81,6 +86,8 @@ if not args.only or "shkadov" in args.only:
 if not args.only or "sloshing" in args.only:
     B = 1024
     env = V.VecSloshing(B, dev, "f32", packaged_init("sloshing"))
+    for o in args.opt:
+        env.set_option(o.split("=")[0], int(o.split("=")[1]))
     env.reset()
     a = torch.as_tensor(rng.uniform(-1, 1, (K + W, B)), dtype=torch.float32, device=dev)
     wall, ms = timed(env, lambda k: env.step(a[k]), K, W)

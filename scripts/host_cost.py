@@ -1,8 +1,12 @@
-"""Host cost of an eager step() call of the 1D envs: wall time per call over a long loop (no events inside), with the
-kernel's own duration (HIP graph replay) next to it; cProfile of the Python side on request.
+"""Host cost of an eager step() call of the 1D envs through both bindings of the C ABI (torch.library ops / ctypes): wall time
+per call over a long loop (no events inside) and the time the host needs to ISSUE the calls, with the kernel's own duration
+(HIP graph replay) next to it; cProfile of the Python side on request.
   PYTHONPATH=. python scripts/host_cost.py [profile]"""
+import os
 import sys
 import time
+
+sys.path.insert(0, os.getcwd())
 
 import torch
 
@@ -15,16 +19,22 @@ for name, mk, shape in (("burgers", lambda: V.VecBurgers(1024, dev, "f32", nx=51
     env = mk()
     env.reset()
     a = torch.zeros(shape, dtype=torch.float32, device=dev).uniform_(-1, 1)
-    for _ in range(50):
-        env.step(a)
-    torch.cuda.synchronize()
     N = 3000 if name != "shkadov" else 300
-    t = time.perf_counter()
-    for _ in range(N):
-        env.step(a)
-    t_issue = time.perf_counter() - t
-    torch.cuda.synchronize()
-    t_all = time.perf_counter() - t
+    for binding in ("torch ops", "ctypes"):             # the two bindings of the same C ABI (beacon_amd/torch_ext.py, _lib.py)
+        if env.use_torch_ops(binding == "torch ops") != (binding == "torch ops"):
+            print("%-9s %s: not available" % (name, binding))
+            continue
+        for _ in range(50):
+            env.step(a)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(N):
+            env.step(a)
+        t_issue = time.perf_counter() - t
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t
+        print("%-9s %-9s eager %.2f us per call, host issue %.2f us per call" % (name, binding, 1e6 * t_all / N, 1e6 * t_issue / N), flush=True)
+    env.use_torch_ops(True)
     g = env.capture(a.unsqueeze(0).expand(16, *a.shape).contiguous(), None, n_steps=16, keep_steps=False)
     g.replay(); torch.cuda.synchronize()
     t = time.perf_counter()
@@ -32,7 +42,7 @@ for name, mk, shape in (("burgers", lambda: V.VecBurgers(1024, dev, "f32", nx=51
         g.replay()
     torch.cuda.synchronize()
     t_graph = (time.perf_counter() - t) / (20 * 16)
-    print("%-9s eager %.2f us per call (host issue %.2f us), in a HIP graph %.2f us" % (name, 1e6 * t_all / N, 1e6 * t_issue / N, 1e6 * t_graph), flush=True)
+    print("%-9s in a HIP graph %.2f us per step" % (name, 1e6 * t_graph), flush=True)
     if len(sys.argv) > 1 and name == "burgers":
         import cProfile
         import pstats

@@ -2,11 +2,14 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from beacon_amd import build
-build.FLAGS.extend(["-DBCN_DBG_NCHK"] + sys.argv[1:]); build.build_lib(force=True)
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("-"))       # name=value -> bcn_set_option
+build.FLAGS.extend(["-DBCN_DBG_NCHK"] + [a for a in sys.argv[1:] if a.startswith("-")]); build.build_lib(force=True)
 from beacon_amd import vec as V
 z = np.load("tests/golden/rayleigh_128x64_init.npz")
 B = 512
 env = V.VecRayleigh(B, "cuda:0", "f32", z["fields"], L=2.56, H=1.28)
+for k_, v_ in opts.items():
+    env.set_option(k_, int(v_))
 env.reset()
 acts = np.random.default_rng(1234).uniform(-1, 1, (3, B, 10))
 for k in range(3):

@@ -1,6 +1,5 @@
 # diagnostic: build variants of the fast kernel (-D flags) and report cycles/sweep + step time
 import os, sys, time, numpy as np, torch
-os.environ.setdefault("BCN_SCHED", "0")
 sys.path.insert(0, os.getcwd())
 from beacon_amd import build
 extra = sys.argv[1:]
@@ -11,6 +10,7 @@ from beacon_amd import vec as V
 z = np.load("tests/golden/rayleigh_128x64_init.npz")
 B = 512
 env = V.VecRayleigh(B, "cuda:0", os.environ.get("BCN_STAMP_DTYPE", "f32"), z["fields"], L=2.56, H=1.28)
+env.set_sched(0)          # plain launch: the stamps are per workgroup = per replica
 env.reset()
 acts = np.random.default_rng(0).uniform(-1, 1, (3, B, 10))
 for k in range(3):

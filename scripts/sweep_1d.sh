@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {   # $1 env, $2 label
   OUT=$ROOT/gpurun_out/sweep1d_tmp
   rm -rf $OUT && mkdir -p $OUT
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/scripts/bench_envs.py --only $1 --steps 20 --no-cpu > $OUT/stdout.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/scripts/bench_envs.py --only $1 --steps 20 --no-cpu $3 > $OUT/stdout.log 2>&1
   echo "$2: $(find $OUT -name '*kernel_stats.csv' -exec grep -h "${1}_step_k" {} \; | sed 's/.*)",//' | cut -d, -f1-3 | tr '\n' ' ') (calls,total_ns,avg_ns)"
   rm -rf $OUT
 }
@@ -19,7 +19,6 @@ if [ "$ENVN" = all ]; then
   for e in burgers shkadov sloshing; do run $e $e; done
 else
   for OW in 1 0; do for K in 1 2 4 8; do
-    export BCN_1D_K=$K BCN_1D_ONEWAVE=$OW
-    run $ENVN "$ENVN K=$K onewave=$OW"
+    run $ENVN "$ENVN K=$K onewave=$OW" "--opt cells_per_thread=$K --opt one_wave=$OW"      # bcn_set_option
   done; done
 fi

@@ -200,6 +200,7 @@ def test_rayleigh_fast_schedulers_match_single_launch():
         "from beacon_amd.envs import packaged_init\n"
         "env = V.VecRayleigh(24, 'cuda:0', 'f64', packaged_init('rayleigh'))\n"
         "assert env.set_variant(1) == 1\n"
+        "env.set_sched(*[int(x) for x in sys.argv[2].split(',')])\n"
         "env.reset()\n"
         "a = np.random.default_rng(5).uniform(-1, 1, (2, 24, 10))\n"
         "for k in range(2): obs, rwd, *_ = env.step(a[k])\n"
@@ -208,11 +209,10 @@ def test_rayleigh_fast_schedulers_match_single_launch():
         " env.get_state().cpu().numpy().ravel(), env.sweeps.cpu().numpy().ravel().astype(float)]))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tag, extra in (("split", dict(BCN_SCHED="1", BCN_LPT_MIN_BATCH="2")), ("single", dict(BCN_SCHED="0")),
-                       ("ticket", dict(BCN_SCHED="2", BCN_SCHED_GRID="5"))):
+    # bcn_set_sched(mode, grid, q, lpt_min_batch) per handle (no environment variable changes the scheduling)
+    for tag, sched in (("split", "1,0,0,2"), ("single", "0,0,0,0"), ("ticket", "2,5,0,0")):
         path = "/tmp/bcn_lpt_%s.npy" % tag
-        env = dict(os.environ, **extra)
-        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code, path, sched], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
     n_obs, B = 24 * 192, 24
@@ -1294,6 +1294,7 @@ def test_mixing_fast2_ticket_scheduler_matches_single_launch():
         "from beacon_amd import vec as V\n"
         "env = V.VecMixing(24, 'cuda:0', 'f32')\n"
         "env.set_ndt_act(60)\n"
+        "env.set_sched(*[int(x) for x in sys.argv[3].split(',')])\n"
         "env.reset()\n"
         "a = np.random.default_rng(5).integers(0, 4, (2, 24))\n"
         "for k in range(2): obs, rwd, *_ = env.step(a[k])\n"
@@ -1303,11 +1304,9 @@ def test_mixing_fast2_ticket_scheduler_matches_single_launch():
         " env.get_state().cpu().numpy().ravel(), env.sweeps.cpu().numpy().ravel().astype(np.float32)]))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tag, kname, extra in (("single", "ns2d_fast2_step", dict(BCN_SCHED="0")),
-                              ("ticket", "ns2d_fast2_sched", dict(BCN_SCHED="2", BCN_SCHED_GRID="5"))):
+    for tag, kname, sched in (("single", "ns2d_fast2_step", "0,0,0,0"), ("ticket", "ns2d_fast2_sched", "2,5,0,0")):
         path = "/tmp/bcn_mix_%s.npy" % tag
-        r = subprocess.run([sys.executable, "-c", code, path, kname], env=dict(os.environ, **extra),
-                           capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code, path, kname, sched], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
     B, ndt = 24, 60
@@ -2448,10 +2447,11 @@ def test_jit_self_check_refuses_a_broken_plugin_and_keeps_the_generic_kernel():
             env = Broken(2, DEV, "f64", None, L=1.5, H=1.0)
         assert getattr(env, "_plugin", None) is None and os.path.exists(path + ".bad")
         ref = V.VecRayleigh(2, DEV, "f64", None, L=1.5, H=1.0)
-        ref.set_variant(0)
         a = np.random.default_rng(1).uniform(-1, 1, (2, 10))
         for e in (env, ref):
             e.set_ndt_act(4)
+            if e is ref:
+                assert e.set_variant(0) == 0          # (set_ndt_act re-creates the handle: the variant is chosen behind it)
             e.reset()
             e.set_state(jit._seeded_rayleigh_state(e))
             e.step(a)
@@ -2477,3 +2477,106 @@ def test_jit_self_check_refuses_a_broken_plugin_and_keeps_the_generic_kernel():
             if os.path.exists(path + mark):
                 os.remove(path + mark)
         jit._LOADED.clear()
+
+
+# ---- the stop rule on an adversarial right-hand side -------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_adversarial_residual_growth_behind_the_stop_sweep_never_moves_the_stop(dtype):
+    """tests/golden/rayleigh_adversarial_50x50.npz: the first solve passes the reference's stop test at sweep 5, and the
+    residual is ABOVE tol again for sweeps 6..15 (the reference's norm d'(I + G)d is not monotone: it can grow by up to 1.030,
+    scripts/weighted_norm_bound.py).  A plan that skips sweep 5 and evaluates in that stretch finds "not converged" and, if it
+    trusted that, would stop up to twelve sweeps late.  Every evaluation plan of the register-resident kernel must return the
+    reference's sweep 5 and the reference's fields -- as it stands and with the test hook that lengthens every skip
+    (plan_overshoot 0..12: the landings then fall on sweeps 5..16); the guarded plan (3, the float32 default) does so because a
+    landing that does not clear BCN_CONV_GUARD * tol is repeated under the proven plan (counters [2], [3]); the UNGUARDED plan 2
+    under the same hook stops late, which is what the guard is for."""
+    g = golden("rayleigh_adversarial_50x50")
+    want = int(g["stop_sweep"])
+    B = 4
+    ref_state = ref_to_dev(g["final_state"])
+
+    def run(opts, variant=1):
+        env = V.VecRayleigh(B, DEV, dtype, None, ra=float(g["ra"]))
+        env.set_ndt_act(1)
+        assert env.set_variant(variant) == variant
+        for k_, v_ in opts.items():
+            env.set_option(k_, v_)
+        env.reset()
+        env.set_state(np.tile(ref_to_dev(g["state"])[None], (B, 1, 1, 1)))
+        env.step(np.zeros((B, 10)))
+        st = env.check_status()
+        out = (env.sweeps[:, 0].cpu().numpy().copy(), env.get_state().double().cpu().numpy(), env.get_counters(), st, env.kernel_name)
+        env.close()
+        return out
+    tol_f = 1e-9 if dtype == "f64" else 2e-6
+    base = run({"conv_plan": 0})
+    assert base[4].startswith("ns2d_fast") and (base[0] == want).all(), (base[4], base[0])
+    assert maxdiff(base[1][0], ref_state) <= tol_f
+    gen = run({}, variant=0)
+    assert (gen[0] == want).all()
+    flagged = 0
+    for plan in (1, 3):
+        for ov in range(0, 13):
+            r = run({"conv_plan": plan, "plan_overshoot": ov})
+            assert (r[0] == want).all(), (plan, ov, r[0])
+            assert np.array_equal(r[1], base[1]), (plan, ov)          # bit for bit the every-sweep result
+            flagged += int(r[2][:, 2].sum()) if plan == 3 else 0
+    assert flagged > 0                                                # the guard did catch unverified landings
+    for plan in (2, 3):
+        r = run({"conv_plan": plan, "verify_conv": 1})
+        assert (r[0] == want).all() and not (r[3] & 4).any(), (plan, r[0], r[3])
+    # the hole the guard closes: the same hook under the unguarded plan stops late for some skip lengths
+    late = [int(run({"conv_plan": 2, "plan_overshoot": ov})[0][0]) for ov in (4, 6, 8, 12)]
+    assert max(late) > want, late
+
+
+# ---- the two bindings of the C ABI (VERDICT r04 item 8) -------------------------------------------------------------
+def test_torch_ops_and_ctypes_bindings_step_every_env_bit_identically():
+    """reset() / step() through torch.ops.beacon.* (csrc/torch/beacon_torch.cpp: one dispatcher call, stream read in C++) and
+    through ctypes call the same bcn_* entry points: three steps, a masked reset and another step of every env family give
+    the same bits -- observations, rewards, done flags, sweep counts, solver state."""
+    from beacon_amd import torch_ext
+    assert torch_ext.load() is not None, "the torch extension is not built (run __graft_entry__.build())"
+    rng = np.random.default_rng(11)
+    B = 6
+    cases = [
+        ("rayleigh", lambda: V.VecRayleigh(B, DEV, "f32", E.packaged_init("rayleigh")), lambda k: rng.uniform(-1, 1, (B, 10)), None),
+        ("mixing", lambda: V.VecMixing(B, DEV, "f32"), lambda k: rng.integers(0, 4, (B,)), None),
+        ("burgers", lambda: V.VecBurgers(B, DEV, "f64", nx=512), lambda k: rng.uniform(-1, 1, (B,)), lambda: rng.uniform(-0.1, 0.1, (B,))),
+        ("shkadov", lambda: V.VecShkadov(B, DEV, "f32", E.packaged_init("shkadov"), n_jets=5), lambda k: rng.uniform(-1, 1, (B, 5)),
+         lambda: rng.uniform(-5e-4, 5e-4, (B, 50))),
+        ("sloshing", lambda: V.VecSloshing(B, DEV, "f64", E.packaged_init("sloshing")), lambda k: rng.uniform(-1, 1, (B,)), None),
+    ]
+    for name, mk, act, nz in cases:
+        acts = [act(k) for k in range(4)]
+        noise = [nz() if nz else None for _ in range(4)]
+        outs = []
+        for use_ops in (True, False):
+            env = mk()
+            assert env.use_torch_ops(use_ops) == use_ops
+            if name in ("rayleigh", "mixing"):
+                env.set_ndt_act(12)
+                env.use_torch_ops(use_ops)
+            log = [env.reset()[0].clone()]
+            for k in range(3):
+                o, r, d, t, _ = env.step(acts[k], noise[k]) if nz else env.step(acts[k])
+                log += [o.clone(), r.clone(), d.clone(), t.clone()]
+            m = torch.tensor([1, 0, 1, 0, 0, 1], dtype=torch.uint8, device=DEV)
+            log.append(env.reset(mask=m)[0].clone())
+            o, r, d, t, _ = env.step(acts[3], noise[3]) if nz else env.step(acts[3])
+            log += [o.clone(), r.clone(), env.get_state()]
+            if hasattr(env, "sweeps"):
+                log.append(env.sweeps.clone())
+            env.check_status()
+            env.close()
+            outs.append(log)
+        assert len(outs[0]) == len(outs[1])
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), name
+    # wrong dtypes / shapes are refused by the op itself, with the library untouched
+    env = V.VecMixing(B, DEV, "f32")
+    with pytest.raises(RuntimeError, match="dtype"):
+        env._ops["mixing_step"](env.h.value, None, env.obs.double(), env.rwd, env.done, env.trunc, env.status, env.sweeps)
+    with pytest.raises(RuntimeError, match="elements"):
+        env._ops["mixing_reset"](env.h.value, env.obs[:2].contiguous())
+    env.close()
