@@ -1454,6 +1454,10 @@ def test_burgers_nx512_vs_oracle_and_mirror():
         for b, o in enumerate(ors):
             ob, rw, _, _, _ = o.step([a[b]], nz[b])
             assert maxdiff(obs[b].cpu().numpy(), ob) <= 1e-12 and maxdiff(float(rwd[b]), rw) <= 1e-12
+        st = env.get_state().cpu().numpy()
+        for b, o in enumerate(ors):       # N = 512 fills the wave exactly: the kernel without per-cell masks (FIT), bit for bit
+            assert np.array_equal(st[b, 0], o.u) and np.array_equal(st[b, 1], o.up) and np.array_equal(st[b, 2], o.upp), (k, b)
+    assert env.kernel_name == "burgers_step_k"
     env.close()
     g = golden("burgers")
     e = E.burgers()
