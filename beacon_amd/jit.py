@@ -215,6 +215,30 @@ def verify(p, make_env, kind, f64):
                       "it is not used: the generic kernel stays selected" % (os.path.basename(p.path), rep))
 
 
+def selftest(device="cuda:0", verbose=False):
+    """The register-resident kernels BUILT INTO libbeacon_hip.so through the comparison that guards a plugin's first use
+    (compare_with_generic: six timesteps of a seeded state, plain launch and ticket scheduler, against the generic kernel).
+    What to run after rebuilding the library with another ROCm / hipcc: these kernels sit at the register limit of the target
+    and their code generation is the compiler's.  Returns {name: (ok, report)}."""
+    from . import vec as V
+    cases = [("rayleigh 128x64", 0, dict(L=2.56, H=1.28), ("f32", "f64")), ("rayleigh 50x50", 0, dict(), ("f32", "f64")),
+             ("rayleigh 100x50", 0, dict(L=2.0), ("f32",)), ("rayleigh 150x50", 0, dict(L=3.0), ("f32",)),
+             ("rayleigh 200x50", 0, dict(L=4.0), ("f32",)), ("rayleigh 100x100", 0, dict(L=2.0, H=2.0), ("f32", "f64")),
+             ("mixing 100x100", 1, dict(), ("f32", "f64"))]
+    out = {}
+    for name, kind, kw, dts in cases:
+        for dt in dts:
+            if kind == 0:
+                mk = lambda B, dt=dt, kw=kw: V.VecRayleigh(B, device, dt, None, **kw)
+            else:
+                mk = lambda B, dt=dt, kw=kw: V.VecMixing(B, device, dt, **kw)
+            ok, rep = compare_with_generic(mk, kind, dt == "f64")
+            out["%s %s" % (name, dt)] = (ok, rep)
+            if verbose:
+                print("%-24s %s  %s" % (name + " " + dt, "ok " if ok else "BAD", rep), flush=True)
+    return out
+
+
 def _signature(defs):
     h = hashlib.sha256()
     h.update(repr((_build.ARCH, _build.FLAGS, _build.FILE_FLAGS.get("ns2d_fast.hip"), sorted(defs.items()))).encode())

@@ -1,7 +1,8 @@
 """Cost of a PLAIN Jacobi sweep of ns2d_fast4_impl.h in isolation: tol = 0 and a small itmax, so that every solve runs
 itmax sweeps, all but two of them without residual (the replica then stops with BCN_ST_ITMAX: timing only).
-  PYTHONPATH=. BEACON_JIT_DEFS="..." python scripts/sweep_cost.py [B]        (BCN_F4_NOBAR / BCN_F4_NOLDS: what a sweep
-  costs without its barrier / without its edge exchange -- wrong results, which is why tol = 0)"""
+  PYTHONPATH=. python scripts/sweep_cost.py [B]
+(Round 4 also built it without its barrier / without its edge exchange -- wrong results, timing only: the sweep is
+issue-bound, docs/history/DESIGN_rounds_1-4.md 4.2c; those switches were removed in round 5.)"""
 import sys
 
 import torch

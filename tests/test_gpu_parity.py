@@ -2584,3 +2584,15 @@ def test_torch_ops_and_ctypes_bindings_step_every_env_bit_identically():
     with pytest.raises(RuntimeError, match="elements"):
         env._ops["mixing_reset"](env.h.value, env.obs[:2].contiguous())
     env.close()
+
+
+def test_builtin_register_resident_kernels_pass_the_plugin_self_check():
+    """beacon_amd.jit.selftest(): every register-resident kernel built into the library (128x64, 50x50, 100/150/200x50,
+    100x100 rayleigh and mixing; float32 and float64 where built) through the comparison that guards an on-demand kernel's
+    first use -- the check to repeat after rebuilding the library with another toolchain."""
+    from beacon_amd import jit
+    res = jit.selftest(DEV)
+    assert len(res) == 11
+    for name, (ok, rep) in res.items():
+        assert ok, (name, rep)
+        assert "ns2d_fast" in rep and "generic" not in rep.split(";")[0], (name, rep)     # the fast kernels did run
