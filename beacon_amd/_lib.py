@@ -93,6 +93,8 @@ SIGNATURES = {
     "bcn_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "bcn_set_noise": (C.c_int, [vp, C.c_double, C.c_uint64, C.c_int64]),
     "bcn_set_sched": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bcn_set_slow_mode_bound": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "bcn_get_slow_mode_bound": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bcn_kernel_name": (C.c_char_p, [vp]),
     "bcn_destroy": (C.c_int, [vp]),
     "bcn_last_error": (C.c_char_p, []),

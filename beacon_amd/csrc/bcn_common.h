@@ -15,6 +15,8 @@
 // scripts/weighted_norm_bound.py (1.0166 in one sweep, the maximum after 4..6 sweeps).  So an evaluation that directly
 // follows skipped sweeps proves that none of them passed the test (err_j <= tol) exactly when it finds err > C tol.
 #define BCN_CONV_GUARD 1.035
+// 1.25 log2(BCN_CONV_GUARD * 1.003): the zone in front of a solve's stop that its speculative opening stays clear of, in bits of err
+#define BCN_OPEN_ZONE_L2 0.0674f
 
 __attribute__((visibility("default"))) void bcn_set_error(const char* fmt, ...);
 
@@ -74,6 +76,8 @@ struct bcn_env_s {
   virtual int set_fast_plugin(void*, size_t) { bcn_set_error("this env takes no kernel plugin"); return BCN_ERR_ARG; }
   virtual int set_noise(double, uint64_t, int64_t) { bcn_set_error("this env has no inlet noise"); return BCN_ERR_ARG; }
   virtual int set_option(const char* name, int) { bcn_set_error("unknown option '%s' for this env", name); return BCN_ERR_ARG; }
+  virtual int set_slow_mode_bound(int, const double*, const double*) { bcn_set_error("this env has no Jacobi solve"); return BCN_ERR_ARG; }
+  virtual int get_slow_mode_bound(double*, double*) const { return 0; }
   virtual int get_counters(uint64_t* host, hipStream_t) { memset(host, 0, (size_t)batch * 4 * sizeof(uint64_t)); return BCN_OK; }   // only the 2D register-resident kernels schedule
   virtual const char* kernel_name() const = 0;
   int32_t* stp = nullptr;  // device int32[B]

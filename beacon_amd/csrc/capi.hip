@@ -1,6 +1,7 @@
 // capi.hip -- extern "C" surface of libbeacon_hip.so (include/beacon_hip.h): handle
 // management, argument-block construction (derived constants are computed here in double and
 // narrowed once), state copies.  All device work is enqueued on the caller's stream.
+#include <math.h>
 #include <stdarg.h>
 
 #include <new>
@@ -100,9 +101,39 @@ struct NS2DEnv : bcn_env_s {
     // without the guess -- measured on the bench workload, repeats per step of 102 400 solves / cycles per sweep: 7/8 27 252 / 916,
     // 6/8 2 021 / 818, 5/8 205 / 827, 4/8 5 / 837, off 0 / 888 (the unverified rule of round 3 landed at 7/8: 740).  mixing's
     // counts drop by up to 9x from one timestep to the next: off; the float64 kernels are built without the jump
-    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 6 : 0;
+    a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 17 : 0;
+    // slow-mode landing guard: the constants of the grids the reference's defaults construct are built in (computed by
+    // beacon_amd/stoprule.py, checked by tests/test_oracle.py); any other grid: bcn_set_slow_mode_bound, else BCN_CONV_GUARD alone
+    static const struct { int nx, ny, kind; double cx, cut[2], cl[2]; } kBuiltin[] = {
+        {128, 64, 0, 0.25, {0.9, 0.8}, {1.00020, 1.00568}},    // rayleigh L = 2.56, H = 1.28 (the bench workload)
+        {50, 50, 0, 0.25, {0.9, 0.8}, {1.00020, 1.00020}},     // rayleigh.py:20-27 defaults L = H = 1
+        {100, 100, 1, 0.25, {0.9, 0.8}, {1.00167, 1.00594}},   // mixing.py:20-28 defaults L = H = 1
+    };
+    for (const auto& e : kBuiltin)
+      if (e.nx == a.nx && e.ny == a.ny && e.kind == a.kind && fabs((double)a.cx - e.cx) < 1e-6) set_slow_mode_bound(2, e.cut, e.cl);
     return BCN_OK;
   }
+  int set_slow_mode_bound(int n, const double* cutoff, const double* bound) override {
+    for (int k = 0; k < n; k++)
+      if (!(cutoff[k] > 0.0 && cutoff[k] < 1.0) || !(bound[k] >= 1.0)) {
+        bcn_set_error("bcn_set_slow_mode_bound: cutoff %g must lie in (0, 1), bound %g must be >= 1", cutoff[k], bound[k]);
+        return BCN_ERR_ARG;
+      }
+    for (int k = 0; k < 2; k++) {
+      a.slow_l2lc[k] = k < n ? (float)log2(cutoff[k]) : 0.f;
+      // rounded UP to float: the kernels compare against it
+      a.slow_cl[k] = k < n ? nextafterf((float)bound[k], INFINITY) : INFINITY;
+      slow_cut[k] = k < n ? cutoff[k] : 0.0;
+    }
+    return BCN_OK;
+  }
+  int get_slow_mode_bound(double* cutoff, double* bound) const override {
+    int n = 0;
+    for (int k = 0; k < 2; k++)
+      if (slow_cut[k] > 0.0) { cutoff[n] = slow_cut[k]; bound[n] = (double)a.slow_cl[k]; n++; }
+    return n;
+  }
+  double slow_cut[2] = {0.0, 0.0};
   ~NS2DEnv() override {
     DeviceGuard g(device);
     fields.release(); work.release(); fscrbuf.release(); obs_hist.release(); a_last.release(); ia_last.release();
@@ -141,7 +172,7 @@ struct NS2DEnv : bcn_env_s {
     }
     if (!strcmp(name, "plan_overshoot") && value >= 0 && value <= 64) { a.plan_overshoot = value; return BCN_OK; }
     if (!strcmp(name, "verify_conv")) { a.verify_conv = value ? 1 : 0; return BCN_OK; }
-    if (!strcmp(name, "spec_start") && value >= 0 && value <= 16) { a.spec_start = value; return BCN_OK; }
+    if (!strcmp(name, "spec_start") && value >= 0 && value <= 17) { a.spec_start = value; return BCN_OK; }
     if (!strcmp(name, "sched_tail") && value >= 0 && value <= 1024) { host.sched_tail = value; return BCN_OK; }
     if (!strcmp(name, "generic_threads") && (value == 0 || value == 256 || value == 1024)) { host.generic_nt = value; return BCN_OK; }
     return bcn_env_s::set_option(name, value);
@@ -632,6 +663,14 @@ int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t replica_offs
 int bcn_set_option(bcn_env_t h, const char* name, int value) {
   if (!h || !name) { bcn_set_error("null handle/name"); return BCN_ERR_ARG; }
   return h->set_option(name, value);
+}
+int bcn_set_slow_mode_bound(bcn_env_t h, int n, const double* cutoff, const double* bound) {
+  if (!h || n < 0 || n > 2 || (n > 0 && (!cutoff || !bound))) { bcn_set_error("bcn_set_slow_mode_bound: null handle/arrays or n outside 0..2"); return BCN_ERR_ARG; }
+  return h->set_slow_mode_bound(n, cutoff, bound);
+}
+int bcn_get_slow_mode_bound(bcn_env_t h, double* cutoff, double* bound) {
+  if (!h || !cutoff || !bound) { bcn_set_error("null handle/arrays"); return BCN_ERR_ARG; }
+  return h->get_slow_mode_bound(cutoff, bound);
 }
 int bcn_set_sched(bcn_env_t h, int mode, int grid, int q, int lpt_min_batch) {
   if (!h) { bcn_set_error("null handle"); return BCN_ERR_ARG; }

@@ -71,6 +71,11 @@ struct NS2DArgs {
   NS2DHost* host;           // host side only (never read by a kernel; may be NULL): see NS2DHost
   real* fscr;               // per-workgroup field scratch of the register-resident kernels whose u, v, T do not
   size_t fscr_stride;       //   fit LDS (float64 128x64): [slots][fscr_stride] elements, slot = workgroup index
+  // slow-mode landing guard of conv_plan 3 (ns2d_fast_impl.h, scripts/weighted_norm_bound.py): log2 of two eigenvalue cutoffs of the
+  // Jacobi matrix and, per cutoff, the bound C_L >= 1 on the growth of the reference norm over any number of sweeps within the span
+  // of the modes above it -- properties of the grid (nx, ny, kind, cx), set by the host (bcn_set_slow_mode_bound); +inf: none
+  float slow_l2lc[2] = {0.f, 0.f};
+  float slow_cl[2] = {__builtin_inff(), __builtin_inff()};
 };
 
 // launchers (one per translation unit)

@@ -719,7 +719,7 @@ __device__ __forceinline__ void fast4_unit(const NS2DArgs<real>& A, const int b,
       //  action for any guess: 60.1 -> 66.1 / 73.0 ms at spec_start 6 / 7)
       constexpr bool SPEC_OPEN = KIND == 0 && RPL >= 2 && std::is_same<real, float>::value;
       if (SPEC_OPEN && A.spec_start > 0 && plan > 1 && !A.verify_conv && prev_min >= 16) {
-        n = ((prev_min * A.spec_start) >> 3) & ~1;
+        n = ((prev_min * (A.spec_start <= 16 ? A.spec_start : 6)) >> 3) & ~1;   // (17 = the zone-aware opening of ns2d_fast_impl.h: 6/8 here)
         if (n > A.itmax) n = A.itmax & ~1;
         if (n > 0) { spec_open = true; BCN_F4_PAIRS(false) __syncthreads(); }
       }

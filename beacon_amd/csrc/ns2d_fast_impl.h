@@ -389,6 +389,16 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   // prev_sweeps[1]: this solve runs under the proven plan (a repeat, conv_plan 3); [2]: solves whose stop sweep the
   // extrapolating plan could not verify ("late stops"); [3]: solves repeated (speculative jump too far, or conv_plan 3)
   if (tid == 0) { prev_sweeps[1] = 0; prev_sweeps[2] = 0; prev_sweeps[3] = 0; }
+  // slow_k (red[24..29]): [0] per timestep, log2 sqrt(3 |d_1|^2 / tol); [1], [3]: log2 of the two mode cutoffs of the slow-mode
+  // landing guard, [2], [4]: their growth bounds (NS2DArgs::slow_*; +inf = none: the guard stays BCN_CONV_GUARD); [5]: -log2 of the
+  // decay of err per sweep at the last planned pair (the next solve's opening).  In LDS, not in registers: read at the ~8
+  // evaluated pairs of a solve only.
+  real* const slow_k = red + 24;
+  if (tid == 0) {
+    slow_k[0] = 0; slow_k[5] = 0;
+    slow_k[1] = (real)A.slow_l2lc[0]; slow_k[2] = (real)A.slow_cl[0];
+    slow_k[3] = (real)A.slow_l2lc[1]; slow_k[4] = (real)A.slow_cl[1];
+  }
 
   // A timestep is software-pipelined against its successor: the ordered part of the scalar transport (rayleigh.py:468-487)
   // is a chain of nx+ny-1 dependent steps that ONE wave walks (transport_chain*), and nothing in the next timestep's
@@ -636,9 +646,20 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     if constexpr (XC == 4) {
       exl(xb, w, 0) = nb[0];
       exl(xb, w, 3) = nb[R - 1];
+      // |d_1|^2 = |phi_1 - 0|^2 = sum nb^2 (plain, interior): what the slow-mode landing guard below scales with.  The partials
+      // travel in the exchange buffer's column slot 1, which the rhs exchange leaves unused, behind the same barrier.
+      real a1p = 0;
+#pragma unroll
+      for (int k = 0; k < R; k++) a1p += nb[k] * nb[k];
+      const real a1w = wave_sum_lane63<real>(a1p);
+      if (lane == 63) exch[((xb * NW + w) * XC + 1) * 64] = a1w;
       __syncthreads();
       nbW = exl(xb, wm, 3);
       nbE = exl(xb, wp, 0);
+      const real a1q = (lane < NW) ? exch[((xb * NW + (lane < NW ? lane : 0)) * XC + 1) * 64] : real(0);
+      const real a1 = read_lane(row16_sum<real>(a1q), 15);
+      // slow_k[0] = log2(sqrt(3 |d_1|^2 / tol)): read again where a landing guard is computed, at least one barrier from here
+      if (tid == 0) slow_k[0] = (real)(0.5f * __log2f(3.f * (float)a1 / (float)A.tol));
       xb ^= 1;
     }
 
@@ -689,8 +710,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     // tolL: what a LANDING evaluation -- the first one behind skipped sweeps -- must exceed for the skip to be verified.  Plan 3:
     // BCN_CONV_GUARD * tol, which PROVES that no skipped sweep passed (bcn_common.h); the plan aims its landings above it.
     // Plan 2: tol itself (only a landing that passes is noticed: the unguarded rule of round 2).
-    const real tolL = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
-    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)tolL * 1.003f);
+    const real tolL0 = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
+    const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)tolL0 * 1.003f);
     constexpr int JMAX = 256;
 #ifdef BCN_DBG_NCHK
     int nchk = 0;
@@ -708,6 +729,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #pragma unroll
     for (int k = 0; k < R; k++) phA[k] = 0;
     finalB = false;
+    real tolL = tolL0;              // the landing guard in force: BCN_CONV_GUARD * tol, or the slow-mode guard of the last evaluation
     int k_prev = -1;                // index of the planned evaluation before the last one, log2 of its two norms
     float l2u_prev = 0, l2w_prev = 0;
     int skip_left = 0;              // verify_conv: sweeps the plan would still skip; -2 / -1: speculative jump pending / failed
@@ -925,7 +947,16 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
           if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
         } else {                                                                             \
           const float l2w1 = __log2f((float)err1), l2w2 = __log2f((float)err2);              \
-          const float room_w = l2w2 - l2tol_w, rho_w = l2w2 - l2w1;                          \
+          float l2tl = l2tol_w;                                                              \
+          if (A.conv_plan == 3) {   /* the slow-mode guard of the landing this skip ends in; the last evaluated sweep is itp */ \
+            const float e0 = (float)slow_k[0], fi = (float)itp;                              \
+            const float t0 = 1.f + 2.f * exp2f(e0 + fi * (float)slow_k[1]), t1 = 1.f + 2.f * exp2f(e0 + fi * (float)slow_k[3]); \
+            const float g = fminf(fminf((float)slow_k[2] * t0 * t0, (float)slow_k[4] * t1 * t1) * 1.001f, (float)BCN_CONV_GUARD); \
+            tolL = A.tol * (real)g;                                                          \
+            l2tl = __log2f((float)tolL * 1.003f);                                            \
+          }                                                                                  \
+          const float room_w = l2w2 - l2tl, rho_w = l2w2 - l2w1;                             \
+          if (SPEC && tid == 0) slow_k[5] = (real)-rho_w;   /* the decay per sweep, for the next solve's opening */ \
           int jw = 0;                                                                        \
           if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
           j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                         \
@@ -950,7 +981,17 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       // at 7/8 of the previous count it almost never is -- measured: nearly every solve repeated)
       if (A.spec_start > 0 && plan > 1 && !A.verify_conv) {
         const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
-        int n0 = ((prev * A.spec_start) >> 3) & ~1;
+        // spec_start 1..16: that many eighths of the previous count.  17 (the default): the count itself moves by a few per cent
+        // from one timestep to the next (0.93 .. 1.05 in the bench workload) -- what the landing must stay clear of is the ZONE in
+        // front of the stop in which err is already below the landing guard, log2(guard) / (decay per sweep) sweeps long (a dozen
+        // at 1.035 and 0.3 % per sweep).  So: 15/16 of the previous count minus 1.25 zones, the decay taken from the previous
+        // solve's last planned pair (slow_k[5]; unknown at the head of a chunk: 6/8 of the count).
+        int n0 = (prev * (A.spec_start <= 16 ? A.spec_start : 6)) >> 3;
+        if (A.spec_start == 17 && plan == 2 && A.conv_plan == 3) {
+          const float rp = (float)slow_k[5];
+          if (rp > 0.f) n0 = ((prev * 15) >> 4) - (int)fminf(ceilf(BCN_OPEN_ZONE_L2 / rp), 4096.f);
+        }
+        n0 = __builtin_amdgcn_readfirstlane(n0) & ~1;
         if (n0 > A.itmax) n0 = A.itmax & ~1;
         if (prev >= 16 && n0 > 0) {
           skip_left = -2;
@@ -978,7 +1019,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       }
       if (SPEC && XC != 4 && itp == 2 && A.spec_start > 0 && plan > 0 && !A.verify_conv) {   // (single-sweep exchange: behind sweeps 1, 2)
         const int prev = __builtin_amdgcn_readfirstlane((int)prev_sweeps[0]);
-        const int ns = ((prev * A.spec_start) >> 3) - 2;
+        const int ns = ((prev * (A.spec_start <= 16 ? A.spec_start : 6)) >> 3) - 2;
         if (prev >= 16 && ns > n) { n = ns & ~1; skip_left = -2; }
       }
       if (n > A.itmax - itp) n = (A.itmax - itp > 0 ? A.itmax - itp : 0) & ~1;   // the overflow test sits in the check sweeps

@@ -223,7 +223,7 @@ def selftest(device="cuda:0", verbose=False):
     from . import vec as V
     cases = [("rayleigh 128x64", 0, dict(L=2.56, H=1.28), ("f32", "f64")), ("rayleigh 50x50", 0, dict(), ("f32", "f64")),
              ("rayleigh 100x50", 0, dict(L=2.0), ("f32",)), ("rayleigh 150x50", 0, dict(L=3.0), ("f32",)),
-             ("rayleigh 200x50", 0, dict(L=4.0), ("f32",)), ("rayleigh 100x100", 0, dict(L=2.0, H=2.0), ("f32", "f64")),
+             ("rayleigh 200x50", 0, dict(L=4.0), ("f32",)), ("rayleigh 100x100", 0, dict(L=2.0, H=2.0), ("f32",)),   # (float64: the generic kernel)
              ("mixing 100x100", 1, dict(), ("f32", "f64"))]
     out = {}
     for name, kind, kw, dts in cases:
@@ -381,6 +381,18 @@ def prebuild(grids=None, verbose=False):
         todo += EXTRA_BUILDS
     with ThreadPoolExecutor(max_workers=int(os.environ.get("BEACON_JIT_JOBS", "4"))) as ex:
         paths = list(ex.map(lambda t: build_plugin(t[0][0], t[0][1], t[0][2], t[0][3], verbose, t[1]), todo))
+    # the slow-mode constants of the same grids (beacon_amd/stoprule.py; only the one-row-per-lane rayleigh kernels use them),
+    # cached in JIT_DIR too: a test on the GPU box then reads them instead of spending a minute of dense algebra
+    from . import stoprule
+    cells = [(nx, ny, kind, 0.25) for (nx, ny, f64, kind), _ in todo]
+    if grids is None:
+        for L, H, f64, kind in fuzz_grids():
+            if kind == 0:
+                dx, dy = float(L / int(50 * L)), float(H / int(50 * H))
+                cells.append((int(50 * L), int(50 * H), kind, dy * dy / (2.0 * (dx * dx + dy * dy))))
+    for nx, ny, kind, cx in sorted(set(cells)):
+        if kind == 0 and ny <= 64 and min(nx, ny) >= 48:
+            stoprule.bounds(nx, ny, kind, cx)
     if os.path.isdir(JIT_DIR):
         # drop the plugins of older source states of THESE grids (same name up to the hash); plugins that users compiled
         # on demand for other grids stay (a stale one is merely unused: build_plugin() compiles the current hash next to it)

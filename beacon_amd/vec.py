@@ -212,6 +212,33 @@ class VecEnv(object):
             _lib.check(self.lib.bcn_set_fast_plugin(self.h, p.fn, p.scratch))
             self._plugin = p
 
+    def _slow_mode_bound(self, kind):
+        """The per-grid constants of conv_plan 3's slow-mode landing guard (beacon_amd/stoprule.py), for grids the library has
+        not built in.  Only the one-row-per-lane kernels (rayleigh, ny <= 64) use them."""
+        if kind != 0 or self.ny > 64 or min(self.nx, self.ny) < 48 or os.environ.get("BEACON_STOPRULE") == "0":
+            return
+        two = C.c_double * 2
+        if self.lib.bcn_get_slow_mode_bound(self.h, two(), two()) > 0:
+            return
+        from . import stoprule
+        cx = self.dy * self.dy / (2.0 * (self.dx * self.dx + self.dy * self.dy))
+        b = stoprule.bounds(self.nx, self.ny, kind, cx)
+        if b:
+            _lib.check(self.lib.bcn_set_slow_mode_bound(self.h, len(b), two(*[c for c, _ in b]), two(*[v for _, v in b])))
+
+    def set_slow_mode_bound(self, pairs):
+        """pairs: up to two (cutoff, bound) of this grid (beacon_amd/stoprule.py: bounds); [] clears them.  The library trusts the
+        caller: constants below the grid's true ones void the proof of conv_plan 3's landings (tests/test_gpu_parity.py shows it)."""
+        two = C.c_double * 2
+        _lib.check(self.lib.bcn_set_slow_mode_bound(self.h, len(pairs), two(*[c for c, _ in pairs]), two(*[b for _, b in pairs])))
+
+    def slow_mode_bound(self):
+        """[(cutoff, bound)] in force (include/beacon_hip.h: bcn_get_slow_mode_bound); empty: the guard is BCN_CONV_GUARD alone."""
+        two = C.c_double * 2
+        c, b = two(), two()
+        n = self.lib.bcn_get_slow_mode_bound(self.h, c, b)
+        return [(c[k], b[k]) for k in range(max(n, 0))]
+
     def use_torch_ops(self, on=True):
         """Switch this env between the two bindings of the C ABI: the torch.library ops (default when the extension is built)
         and ctypes.  Returns whether the ops are in use.  Results do not depend on it (tests/test_gpu_parity.py)."""
@@ -422,6 +449,7 @@ class VecRayleigh(VecEnv):
         _lib.check(self.lib.bcn_rayleigh_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
                                                 C.byref(self.h)))
         self._attach_plugin(0)
+        self._slow_mode_bound(0)
 
     def set_ndt_act(self, n):
         """Test hook: shorten the action step (the goldens for big grids use ndt_act=5)."""

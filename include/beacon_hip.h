@@ -258,6 +258,18 @@ BCN_API int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t repl
  * No environment variable changes any of these (round 5: the library reads none).
  * Returns BCN_ERR_ARG for unknown names. */
 BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
+/* Slow-mode landing guard of conv_plan 3 (no reference counterpart; beacon_amd/stoprule.py has the derivation).  Within the span of
+ * the Jacobi matrix's eigenvectors with |lambda| >= cutoff[k], the reference norm can grow from a sweep to any later one by at most
+ * bound[k] (>= 1: 1.0002 / 1.0057 for cutoffs 0.9 / 0.8 on the 128x64 grid, against 1.030 over all modes), and what lies outside that
+ * span has decayed to cutoff^(j-1) |d_1| by sweep j.  With the constants set, a landing behind the last evaluated sweep i is verified
+ * when it finds err > min(BCN_CONV_GUARD, min_k bound[k] (1 + 2 sqrt(3 |d_1|^2 / tol) cutoff[k]^i)^2 (1 + 0.001)) tol -- a fraction of
+ * a percent above tol late in a solve instead of 3.5 %, i.e. a dozen sweeps fewer that must be evaluated one by one.  The constants
+ * are properties of (nx, ny, boundary kind, cx): built in for the reference's default grids (rayleigh 50x50, mixing 100x100) and for
+ * 128x64; for any other grid the host computes them (beacon_amd/stoprule.py, cached) and passes n <= 2 pairs here; n = 0 clears them
+ * (the guard is then BCN_CONV_GUARD alone).  Used by the one-row-per-lane kernels' paired evaluations (ny <= 64); other kernels keep
+ * BCN_CONV_GUARD.  bcn_get_slow_mode_bound returns the number of pairs in force and writes them (arrays of 2). */
+BCN_API int bcn_set_slow_mode_bound(bcn_env_t h, int n, const double* cutoff, const double* bound);
+BCN_API int bcn_get_slow_mode_bound(bcn_env_t h, double* cutoff, double* bound);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference
  * counterpart: the reference steps one env per process, rayleigh.py:138-157).  mode: -1 = default
  * (2), 0 = one workgroup per replica in one launch, 1 = two launches with the

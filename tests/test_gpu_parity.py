@@ -979,11 +979,12 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
     """ns2d_fast_impl.h starts a Jacobi solve with spec_start/8 of the previous timestep's sweep count as double sweeps
     before the first evaluation of the residual (the norm never increases, so a first evaluation that does not pass
     proves that no earlier sweep did) and repeats the solve in the ordinary way when that first evaluation passes.
-    spec_start = 16 (twice the previous count) overshoots in every timestep and so runs the repeat path; all settings must
+    spec_start = 16 (twice the previous count) overshoots in every timestep and so runs the repeat path; 17 is the default:
+    15/16 of the previous count minus the zone in which the residual is already below the landing guard; all settings must
     give the sweep counts and fields of spec_start = 0 bit for bit (full action step of the bench workload, 200 timesteps,
     ticket scheduler and plain launch).  The float64 kernels are built without the jump: there the option must be inert."""
     ref = {}
-    for spec, sched in ((0, 0), (4, 0), (7, 0), (16, 0), (0, 2), (6, 2), (16, 2)):
+    for spec, sched in ((0, 0), (4, 0), (7, 0), (16, 0), (17, 0), (0, 2), (6, 2), (16, 2), (17, 2)):
         env, init, acts = _bench_workload(300, 1, dtype)
         env.set_option("spec_start", spec)
         env.set_sched(sched)
@@ -2532,6 +2533,71 @@ def test_adversarial_residual_growth_behind_the_stop_sweep_never_moves_the_stop(
     # the hole the guard closes: the same hook under the unguarded plan stops late for some skip lengths
     late = [int(run({"conv_plan": 2, "plan_overshoot": ov})[0][0]) for ov in (4, 6, 8, 12)]
     assert max(late) > want, late
+    # ... and so does the guarded plan when it is handed slow-mode constants that are NOT this grid's (a cutoff of 1e-4 with
+    # bound 1 claims that everything but the constant has decayed after one sweep: the landing guard collapses to 1.001 tol)
+    late = []
+    for ov in (4, 6, 8, 12):
+        env = V.VecRayleigh(B, DEV, dtype, None, ra=float(g["ra"]))
+        env.set_ndt_act(1)
+        assert env.set_variant(1) == 1 and len(env.slow_mode_bound()) == 2          # 50x50: built in
+        env.set_slow_mode_bound([(1.0e-4, 1.0)])
+        env.set_option("conv_plan", 3)
+        env.set_option("plan_overshoot", ov)
+        env.reset()
+        env.set_state(np.tile(ref_to_dev(g["state"])[None], (B, 1, 1, 1)))
+        env.step(np.zeros((B, 10)))
+        late.append(int(env.sweeps[0, 0]))
+        env.close()
+    if dtype == "f32":               # (the float64 50x50 kernel evaluates sweep by sweep: its guard is BCN_CONV_GUARD whatever the constants)
+        assert max(late) > want, late
+
+
+def test_slow_mode_landing_guard_never_changes_a_result():
+    """conv_plan 3 verifies a landing against min(BCN_CONV_GUARD, the slow-mode guard) * tol (include/beacon_hip.h:
+    bcn_set_slow_mode_bound; beacon_amd/stoprule.py).  With the grid's constants (built in for 128x64; computed at creation for a
+    JIT grid), without them (guard 1.035 alone) and with every sweep evaluated (conv_plan 0) the sweep counts and fields of a
+    full action step of the bench workload are the same bits, no landing is left unverified -- and the constants pay: fewer
+    cycles inside the Jacobi loop than without them."""
+    got = {}
+    for name in ("slow", "global", "literal"):
+        env, init, acts = _bench_workload(300, 1, "f32")
+        have = env.slow_mode_bound()
+        assert [c for c, _ in have] == [0.9, 0.8] and all(1.0 <= b < 1.01 for _, b in have), have
+        if name == "global":
+            env.set_slow_mode_bound([])
+            assert env.slow_mode_bound() == []
+        if name == "literal":
+            env.set_option("conv_plan", 0)
+        env.step(acts[0])
+        env.check_status()
+        c = env.get_counters()
+        got[name] = (env.sweeps.clone(), env.get_state().clone(), env.obs.clone(), float(c[:, 0].sum()), int(c[:, 2].sum()))
+        env.close()
+    for name in ("global", "literal"):
+        for a, b in zip(got["slow"][:3], got[name][:3]):
+            assert torch.equal(a, b), name
+    assert got["slow"][4] == 0 and got["global"][4] == 0            # plan 3 leaves no unverified stop behind
+    assert got["slow"][3] < 0.99 * got["global"][3] < 0.99 * got["literal"][3], [got[k][3] for k in got]
+    # a grid whose constants the host computes (75x50: beacon_amd/stoprule.py, cached beside its kernel plugin)
+    ref = None
+    for plan in (3, 0):
+        env = V.VecRayleigh(6, DEV, "f32", None, L=1.5, H=1.0)
+        env.set_ndt_act(30)
+        assert env.set_variant(1) == 1 and len(env.slow_mode_bound()) == 2, env.slow_mode_bound()
+        env.set_option("conv_plan", plan)
+        x, y = (np.arange(env.nx + 2) - 0.5) / env.nx, (np.arange(env.ny + 2) - 0.5) / env.ny
+        st0 = np.zeros((4, env.nx + 2, env.ny + 2))
+        st0[3] = (0.5 - y)[None, :] + 0.08 * np.sin(2 * np.pi * x * 1.5)[:, None] * np.sin(np.pi * y)[None, :]
+        env.reset()
+        env.set_state(np.tile(ref_to_dev(st0)[None], (6, 1, 1, 1)))
+        env.step(np.random.default_rng(3).uniform(-1, 1, (6, 10)))
+        env.check_status()
+        out = (env.sweeps.clone(), env.get_state().clone())
+        env.close()
+        if ref is None:
+            ref = out
+        else:
+            assert torch.equal(ref[0], out[0]) and torch.equal(ref[1], out[1])
 
 
 # ---- the two bindings of the C ABI (VERDICT r04 item 8) -------------------------------------------------------------
@@ -2588,11 +2654,11 @@ def test_torch_ops_and_ctypes_bindings_step_every_env_bit_identically():
 
 def test_builtin_register_resident_kernels_pass_the_plugin_self_check():
     """beacon_amd.jit.selftest(): every register-resident kernel built into the library (128x64, 50x50, 100/150/200x50,
-    100x100 rayleigh and mixing; float32 and float64 where built) through the comparison that guards an on-demand kernel's
+    100x100 rayleigh (float32) and mixing; float32 and float64 where built) through the comparison that guards an on-demand kernel's
     first use -- the check to repeat after rebuilding the library with another toolchain."""
     from beacon_amd import jit
     res = jit.selftest(DEV)
-    assert len(res) == 11
+    assert len(res) == 10
     for name, (ok, rep) in res.items():
         assert ok, (name, rep)
         assert "ns2d_fast" in rep and "generic" not in rep.split(";")[0], (name, rep)     # the fast kernels did run

@@ -332,3 +332,75 @@ def test_adversarial_fixture_residual_rises_above_tol_behind_the_reference_stop_
     assert int(env.itp[0]) == int(g["stop_sweep"]) == 5
     for i in range(4):
         assert np.array_equal(env.st[i], g["final_state"][i])
+
+
+def test_slow_mode_bound_holds_on_explicit_sweeps_and_is_attained():
+    """beacon_amd/stoprule.py: within the span of the Jacobi matrix's eigenvectors with |lambda| >= lc the reference norm grows
+    by at most C_L over any number of sweeps, and an arbitrary increment d_1 obeys  err_k <= C_L (1 + 2 e_j)^2 err_j  for all
+    j < k with e_j = sqrt(3) lc^(j-1) sqrt(|d_1|^2 / err_j) -- the inequality the kernels' landing guard rests on.  Checked
+    here on explicit sweeps of the reference's update (scripts/weighted_norm_bound.py: operators) for random right-hand sides,
+    smooth ones, and the maximiser of the slow span itself (which must ATTAIN C_L: the constant is not slack)."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import weighted_norm_bound as W
+    from beacon_amd import stoprule as S
+    rng = np.random.default_rng(7)
+    for nx, ny, kind, cx, lc in ((64, 24, 0, 0.25, 0.8), (40, 30, 1, 0.3, 0.75), (90, 20, 0, 0.22, 0.85)):
+        J, sw, P = W.operators(nx, ny, kind, cx)
+        lam, g0, B = S.slow_span(nx, ny, kind, cx, lc, basis=True)
+        # the basis really is J's: J B = B diag(lam), B'B = I, and G0 is W on it
+        jb = np.stack([J(B[:, k].reshape(nx, ny)).ravel() for k in range(0, B.shape[1], 7)], axis=1)
+        assert np.abs(jb - B[:, ::7] * lam[::7]).max() < 1e-12 and np.abs(B.T @ B - np.eye(len(lam))).max() < 1e-12
+        assert np.abs(B.T @ ((sw.ravel() ** 2)[:, None] * B) - g0).max() < 1e-12
+        ms = list(range(1, 41)) + [48, 64, 96, 128, 256]
+        cm = S.growth_in_span(lam, g0, ms, vectors=True)
+        c_l = max(1.0, max(c for c, _ in cm))
+        kbest = int(np.argmax([c for c, _ in cm]))
+
+        def errs(d, n):
+            out = []
+            for _ in range(n):
+                out.append(float(((sw * d) ** 2).sum()))
+                d = J(d)
+            return np.array(out)
+        # the maximiser attains C(m) on explicit sweeps
+        c_top, x = cm[kbest]
+        e = errs((B @ x).reshape(nx, ny), ms[kbest] + 1)
+        assert abs(e[ms[kbest]] / e[0] - c_top) < 1e-6 * c_top
+        # vectors of the slow span never exceed C_L, whatever the lag
+        for _ in range(20):
+            e = errs((B @ rng.standard_normal(len(lam))).reshape(nx, ny), 80)
+            ratio = e[None, :] / e[:, None]
+            assert np.triu(ratio, 1).max() <= c_l * (1 + 1e-9)
+        # arbitrary increments: the guard inequality for every j < k
+        worst = 0.0
+        for trial in range(12):
+            d1 = rng.standard_normal((nx, ny)) * (1.0 if trial % 3 else 0.05) + (B @ (x * 3 * rng.standard_normal())).reshape(nx, ny)
+            d1 = P(d1)
+            a1 = float((d1 * d1).sum())
+            e = errs(d1, 70)
+            jj = np.arange(1, 71)
+            eps = np.sqrt(3.0) * lc ** (jj - 1) * np.sqrt(a1 / e)               # e_j with tol := err_j
+            bound = c_l * (1 + 2 * eps) ** 2 * e                                 # bound on err_k for every k > j
+            for j in range(70):
+                worst = max(worst, float((e[j + 1:] / bound[j]).max()) if j < 69 else 0.0)
+        assert worst <= 1.0 + 1e-9, worst
+
+
+def test_builtin_slow_mode_constants_match_the_script():
+    """capi.hip has the slow-mode constants of the reference's default grids and of the bench grid built in; each must be at
+    or above what beacon_amd/stoprule.py computes for that grid (and not more than 5e-4 above: not slack either)."""
+    import os
+    import re
+    from conftest import ROOT
+    from beacon_amd import stoprule as S
+    src = open(os.path.join(ROOT, "beacon_amd", "csrc", "capi.hip")).read()
+    rows = re.findall(r"\{(\d+), (\d+), (\d), ([0-9.]+), \{([0-9.]+), ([0-9.]+)\}, \{([0-9.]+), ([0-9.]+)\}\}", src)
+    assert len(rows) >= 3
+    for nx, ny, kind, cx, c0, c1, b0, b1 in rows:
+        assert (float(c0), float(c1)) == S.CUTOFFS
+        for lc, have in ((float(c0), float(b0)), (float(c1), float(b1))):
+            want = S.bound(int(nx), int(ny), int(kind), float(cx), lc)
+            assert want - 1e-6 <= have <= want + 5e-4, (nx, ny, kind, lc, have, want)
