@@ -312,6 +312,14 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
   // under the proven plan (conv_plan 3): see the end of the Jacobi loop.  Written and read by thread 0 only.
   real* const guard = red + 21;
   if (tid == 0) { guard[0] = 0; guard[1] = 0; }
+  // slow_k (red[26..30]; red[24..25] are the scheduler's words): the slow-mode landing guard of conv_plan 3, as in ns2d_fast_impl.h --
+  // [0] per solve, log2 sqrt(3 |d_1|^2 / tol); [1], [3]: log2 of the two mode cutoffs; [2], [4]: their growth bounds
+  real* const slow_k = red + 26;
+  if (tid == 0) {
+    slow_k[0] = 0;
+    slow_k[1] = (real)A.slow_l2lc[0]; slow_k[2] = (real)A.slow_cl[0];
+    slow_k[3] = (real)A.slow_l2lc[1]; slow_k[4] = (real)A.slow_cl[1];
+  }
   for (int it = it_begin; it < it_end && status == 0; it++) {
     // fields in the global scratch: keep hipcc from hoisting the (64-bit) addresses of a whole timestep out of the loop
     if (GF) asm volatile("" : "+v"(j0));
@@ -511,6 +519,20 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 
     BCN_PH(1)
     const unsigned long long cyc_j0 = __builtin_amdgcn_s_memtime();
+    if (A.conv_plan == 3) {
+      // |d_1|^2 = |phi_1 - 0|^2 = sum nb^2 (plain, interior): what the slow-mode landing guard scales with (ns2d_fast_impl.h).  One
+      // barrier per solve; the partials go to the errp half the first evaluated sweep does not write.
+      real a1p = 0;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < RW; k++) a1p += NB(a, k) * NB(a, k);
+      const real a1w = wave_sum_lane63<real>(a1p);
+      if (lane == 63) errp[(xb ^ 1) * 32 + w] = a1w;
+      __syncthreads();
+      const real a1 = read_lane(row16_sum<real>(errp[(xb ^ 1) * 32 + (lane & 15)]), 15);
+      if (tid == 0) slow_k[0] = (real)(0.5f * __log2f(3.f * (float)a1 / (float)A.tol));
+    }
     // ---- Jacobi sweeps: one barrier per sweep, phi ping-pong in registers ---------------------
     // The residual is evaluated only on the sweeps that can pass the test (A.conv_plan, see ns2d_fast.hip); a sweep
     // that evaluates it does so behind its own barrier, with the arithmetic the fused form had.
@@ -534,7 +556,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     int skip_left = 0;
     // tolL: what a landing evaluation -- the first one behind skipped sweeps -- must exceed for the skip to be verified: under
     // plan 3 BCN_CONV_GUARD * tol, which proves that no skipped sweep passed (bcn_common.h); under plan 2 tol itself
-    const real tolL = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
+    // (plan 3: until the first evaluation, then the smaller of that and the slow-mode guard behind the last evaluated sweep)
+    real tolL = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
     const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)tolL * 1.003f);
     constexpr int JMAX = 256;
     // lower row (a = 0): south = lane below's upper row (DPP), north = own upper row;
@@ -630,7 +653,15 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
             const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;                       \
             if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX;   \
           } else {                                                                                   \
-            const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;                       \
+            float l2tl = l2tol_w;                                                                    \
+            if (A.conv_plan == 3) {   /* the slow-mode guard of the landing this skip ends in; this sweep, itp, is the last evaluated one */ \
+              const float e0 = (float)slow_k[0], fi = (float)itp;                                    \
+              const float t0 = 1.f + 2.f * exp2f(e0 + fi * (float)slow_k[1]), t1 = 1.f + 2.f * exp2f(e0 + fi * (float)slow_k[3]); \
+              const float g = fminf(fminf((float)slow_k[2] * t0 * t0, (float)slow_k[4] * t1 * t1) * 1.001f, (float)BCN_CONV_GUARD); \
+              tolL = A.tol * (real)g;                                                                \
+              l2tl = __log2f((float)tolL * 1.003f);                                                  \
+            }                                                                                        \
+            const float room_w = l2w - l2tl, rho_w = (l2w - l2w_prev) * rg;                          \
             int jw = 0;                                                                              \
             if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX;  \
             j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                                                  \

@@ -661,6 +661,17 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       // slow_k[0] = log2(sqrt(3 |d_1|^2 / tol)): read again where a landing guard is computed, at least one barrier from here
       if (tid == 0) slow_k[0] = (real)(0.5f * __log2f(3.f * (float)a1 / (float)A.tol));
       xb ^= 1;
+    } else if (A.conv_plan == 3) {
+      // (single-sweep exchange: no rhs exchange to ride on -- one barrier per solve; the partials go to the errp half that the
+      // first evaluated sweep does not write)
+      real a1p = 0;
+#pragma unroll
+      for (int k = 0; k < R; k++) a1p += nb[k] * nb[k];
+      const real a1w = wave_sum_lane63<real>(a1p);
+      if (lane == 63) errp[(xb ^ 1) * 64 + w] = a1w;
+      __syncthreads();
+      const real a1 = read_lane(row16_sum<real>(errp[(xb ^ 1) * 64 + (lane & 15)]), 15);
+      if (tid == 0) slow_k[0] = (real)(0.5f * __log2f(3.f * (float)a1 / (float)A.tol));
     }
 
     BCN_PH(1)
@@ -850,7 +861,15 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
             const float room_u = l2u - l2tol_u, rho_u = (l2u - l2u_prev) * rg;               \
             if (room_u > 0.f) j = (rho_u < 0.f) ? (int)fminf(room_u / -rho_u, (float)JMAX) : JMAX; \
           } else {                                                                           \
-            const float room_w = l2w - l2tol_w, rho_w = (l2w - l2w_prev) * rg;               \
+            float l2tl = l2tol_w;                                                            \
+            if (A.conv_plan == 3) {   /* the slow-mode guard of the landing this skip ends in; this sweep, itp, is the last evaluated one */ \
+              const float e0 = (float)slow_k[0], fi = (float)itp;                            \
+              const float t0 = 1.f + 2.f * exp2f(e0 + fi * (float)slow_k[1]), t1 = 1.f + 2.f * exp2f(e0 + fi * (float)slow_k[3]); \
+              const float g = fminf(fminf((float)slow_k[2] * t0 * t0, (float)slow_k[4] * t1 * t1) * 1.001f, (float)BCN_CONV_GUARD); \
+              tolL = A.tol * (real)g;                                                        \
+              l2tl = __log2f((float)tolL * 1.003f);                                          \
+            }                                                                                \
+            const float room_w = l2w - l2tl, rho_w = (l2w - l2w_prev) * rg;                  \
             int jw = 0;                                                                      \
             if (room_w > 0.f) jw = (rho_w < 0.f) ? (int)fminf(room_w / -rho_w, (float)JMAX) : JMAX; \
             j = jw - 1 - (jw >> 4) + A.plan_overshoot;                                                          \

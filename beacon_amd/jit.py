@@ -387,11 +387,11 @@ def prebuild(grids=None, verbose=False):
     cells = [(nx, ny, kind, 0.25) for (nx, ny, f64, kind), _ in todo]
     if grids is None:
         for L, H, f64, kind in fuzz_grids():
-            if kind == 0:
-                dx, dy = float(L / int(50 * L)), float(H / int(50 * H))
-                cells.append((int(50 * L), int(50 * H), kind, dy * dy / (2.0 * (dx * dx + dy * dy))))
+            n = 50 if kind == 0 else 100
+            dx, dy = float(L / int(n * L)), float(H / int(n * H))
+            cells.append((int(n * L), int(n * H), kind, dy * dy / (2.0 * (dx * dx + dy * dy))))
     for nx, ny, kind, cx in sorted(set(cells)):
-        if kind == 0 and ny <= 64 and min(nx, ny) >= 48:
+        if ny <= 128 and min(nx, ny) >= 48:
             stoprule.bounds(nx, ny, kind, cx)
     if os.path.isdir(JIT_DIR):
         # drop the plugins of older source states of THESE grids (same name up to the hash); plugins that users compiled

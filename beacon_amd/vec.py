@@ -214,8 +214,8 @@ class VecEnv(object):
 
     def _slow_mode_bound(self, kind):
         """The per-grid constants of conv_plan 3's slow-mode landing guard (beacon_amd/stoprule.py), for grids the library has
-        not built in.  Only the one-row-per-lane kernels (rayleigh, ny <= 64) use them."""
-        if kind != 0 or self.ny > 64 or min(self.nx, self.ny) < 48 or os.environ.get("BEACON_STOPRULE") == "0":
+        not built in.  The one-row and two-rows-per-lane kernels (ny <= 128) use them; the hybrid and the generic kernel do not."""
+        if self.ny > 128 or min(self.nx, self.ny) < 48 or os.environ.get("BEACON_STOPRULE") == "0":
             return
         two = C.c_double * 2
         if self.lib.bcn_get_slow_mode_bound(self.h, two(), two()) > 0:
@@ -556,6 +556,7 @@ class VecMixing(VecEnv):
         _lib.check(self.lib.bcn_mixing_create(C.byref(c), self.batch, self.cdtype, self.dev_index,
                                               C.byref(self.h)))
         self._attach_plugin(1)
+        self._slow_mode_bound(1)
 
     def set_ndt_act(self, n):
         self.close()

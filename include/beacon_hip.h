@@ -266,8 +266,8 @@ BCN_API int bcn_set_option(bcn_env_t h, const char* name, int value);
  * a percent above tol late in a solve instead of 3.5 %, i.e. a dozen sweeps fewer that must be evaluated one by one.  The constants
  * are properties of (nx, ny, boundary kind, cx): built in for the reference's default grids (rayleigh 50x50, mixing 100x100) and for
  * 128x64; for any other grid the host computes them (beacon_amd/stoprule.py, cached) and passes n <= 2 pairs here; n = 0 clears them
- * (the guard is then BCN_CONV_GUARD alone).  Used by the one-row-per-lane kernels' paired evaluations (ny <= 64); other kernels keep
- * BCN_CONV_GUARD.  bcn_get_slow_mode_bound returns the number of pairs in force and writes them (arrays of 2). */
+ * (the guard is then BCN_CONV_GUARD alone).  Used by the one-row and two-rows-per-lane kernels (ny <= 128); the hybrid kernel
+ * (ny > 128) keeps BCN_CONV_GUARD.  bcn_get_slow_mode_bound returns the number of pairs in force and writes them (arrays of 2). */
 BCN_API int bcn_set_slow_mode_bound(bcn_env_t h, int n, const double* cutoff, const double* bound);
 BCN_API int bcn_get_slow_mode_bound(bcn_env_t h, double* cutoff, double* bound);
 /* Work scheduling of the register-resident 2D kernels when replicas outnumber the CUs (no reference

