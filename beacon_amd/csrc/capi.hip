@@ -339,7 +339,7 @@ struct Env1D : bcn_env_s {
   void set_mask(const uint8_t* m) override { a.mask = m; }
   int set_option(const char* name, int value) override {
     if (!strcmp(name, "cells_per_thread") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { a.force_k = value; return BCN_OK; }
-    if (!strcmp(name, "one_wave") && (value == 0 || value == 1)) { a.one_wave = value; return BCN_OK; }
+    if (!strcmp(name, "one_wave") && value >= 0 && value <= 2) { a.one_wave = value; return BCN_OK; }   // 2: without the packed float32 kernel
     return bcn_env_s::set_option(name, value);
   }
 };

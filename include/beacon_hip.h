@@ -242,15 +242,19 @@ BCN_API int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t repl
  *                     reference's constructor space), so had a skipped sweep passed, the landing would find err <= 1.030 tol;
  *                     a landing above BCN_CONV_GUARD = 1.035 tol therefore proves that none did, and a landing below it is
  *                     counted ([2]) and the solve repeated under plan 1 (the default of both precisions; grids with a side below 48
- *                     cells, where the bound is larger, take plans 0 / 1 only);
+ *                     cells, where the bound is larger, take plans 0 / 1 only).  With the grid's slow-mode constants in force
+ *                     (bcn_set_slow_mode_bound below; built in for the default grids) the landing threshold drops from 1.035 tol
+ *                     to a fraction of a percent above tol late in a solve -- still a proof, and far fewer evaluations;
  *                 2 = plan 3's extrapolation WITHOUT the verification (round 2's rule: it notices a landing only when the
  *                     landing itself passes, and then only counts it): kept for measurements, never a default
  *   "plan_overshoot" 0..64, TEST HOOK: lengthens every skip of plans 2 / 3 by that many sweeps, so that landings fall behind
  *                 the stop sweep (tests/test_gpu_parity.py: the adversarial right-hand side)
  *   "verify_conv" 1 = evaluate every sweep anyway and raise BCN_ST_PLAN if a sweep the plan skips passes the test
- *   "spec_start"  0..16: open a solve with unevaluated double sweeps up to spec_start/8 of the previous timestep's sweep
- *                 count; the landing behind them is verified like any other (plan 3: above 1.035 tol, else the solve is
- *                 repeated without the guess).  BCN_F32 rayleigh only (default 6); ignored by BCN_F64 handles, off for mixing
+ *   "spec_start"  0..17: open a solve with unevaluated double sweeps up to spec_start/8 of the previous timestep's sweep
+ *                 count (1..16), or -- 17, the default -- up to 15/16 of it minus 1.25 times the stretch in front of the stop in
+ *                 which the residual is already below the landing guard (log2(1.035) / the previous solve's decay per sweep);
+ *                 the landing behind them is verified like any other (plan 3: above 1.035 tol, else the solve is
+ *                 repeated without the guess).  BCN_F32 rayleigh only; ignored by BCN_F64 handles, off for mixing
  *   "sched_tail"  short chunks that end a step of the ticket scheduler (0 = default 6; see bcn_set_sched)
  *   "generic_threads" 256 / 1024: workgroup size of the generic 2D kernel (0 = chosen by grid size)
  *   "cells_per_thread" (1D envs) 1, 2, 4, 8 cells per thread (0 = chosen from grid and batch); "one_wave" (1D envs) 0 / 1:
