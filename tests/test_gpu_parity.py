@@ -1771,6 +1771,40 @@ def test_env1d_float64_bit_identical_to_oracle():
     env.close()
 
 
+def test_sloshing_packed_float32_kernel_matches_the_unpacked_one_and_the_oracle():
+    """float32 sloshing at the reference's grid runs sloshing_step_pk_k (one wave, two cells per v_pk instruction, fluxes per face,
+    walls as selects); option one_wave = 2 selects the kernel it replaces.  40 action steps with random actions from the packaged
+    developed state: measured (scripts/burgers_pk_diff.py) both kernels sit at the same distance from the float64 oracle -- h 2e-7
+    after one step, 3e-6 after 40; q 6e-7 / 1.2e-5 -- and differ from each other by as much; the right-hand-side arrays are flux
+    differences times 1 / dx = 80 (values up to 25: an ulp of the flux is 2e-6, 1.5e-4 after the division), so their bound is 2e-3."""
+    init = E.packaged_init("sloshing")
+    rng = np.random.default_rng(3)
+    B = 6
+    envs = []
+    for ow in (1, 2):
+        e = V.VecSloshing(B, DEV, "f32", init)
+        e.set_option("one_wave", ow)
+        e.reset()
+        envs.append(e)
+    ors = [O.sloshing(init_fields=init) for _ in range(B)]
+    for o in ors:
+        o.reset()
+    for k in range(40):
+        a = rng.uniform(-1, 1, B)
+        outs = [e.step(a) for e in envs]
+        st = [e.get_state().double().cpu().numpy() for e in envs]
+        assert maxdiff(st[0][:, :2], st[1][:, :2]) <= 4e-5 and maxdiff(st[0][:, 2:], st[1][:, 2:]) <= 2e-3, k
+        assert maxdiff(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy()) <= 4e-5 and maxdiff(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 1e-6
+        assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+        for b, o in enumerate(ors):
+            ob, rw, dn, tr, _ = o.step([a[b]])
+            assert maxdiff(st[0][b, 0], o.h) <= 2e-5 and maxdiff(st[0][b, 1], o.q) <= 6e-5, (k, b)
+            assert maxdiff(outs[0][0][b].double().cpu().numpy(), ob) <= 6e-5 and abs(float(outs[0][1][b]) - rw) <= 1e-6
+            assert bool(outs[0][2][b]) == bool(dn) and bool(outs[0][3][b]) == bool(tr)
+    for e in envs:
+        e.close()
+
+
 def test_sloshing_blowup_flag():
     env = V.VecSloshing(2, DEV, "f64", None)
     env.reset()
