@@ -88,6 +88,24 @@ __device__ __forceinline__ real wave_sum_lane63(real s) {  // lane 63: sum over 
   s += dpp<0x143, 0xc, 0xf, false>(real(0), s);
   return s;
 }
+// the same with max, for NON-NEGATIVE values (lanes without a source read 0)
+__device__ __forceinline__ float bcn_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double bcn_fmax(double a, double b) { return __builtin_fmax(a, b); }
+template <typename real>
+__device__ __forceinline__ real row16_max(real s) {
+  s = bcn_fmax(s, dpp<0x111, 0xf, 0xf, true>(real(0), s));
+  s = bcn_fmax(s, dpp<0x112, 0xf, 0xf, true>(real(0), s));
+  s = bcn_fmax(s, dpp<0x114, 0xf, 0xf, true>(real(0), s));
+  s = bcn_fmax(s, dpp<0x118, 0xf, 0xf, true>(real(0), s));
+  return s;
+}
+template <typename real>
+__device__ __forceinline__ real wave_max_lane63(real s) {
+  s = row16_max(s);
+  s = bcn_fmax(s, dpp<0x142, 0xa, 0xf, false>(real(0), s));
+  s = bcn_fmax(s, dpp<0x143, 0xc, 0xf, false>(real(0), s));
+  return s;
+}
 __device__ __forceinline__ float read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }

@@ -102,6 +102,9 @@ struct NS2DEnv : bcn_env_s {
     // 6/8 2 021 / 818, 5/8 205 / 827, 4/8 5 / 837, off 0 / 888 (the unverified rule of round 3 landed at 7/8: 740).  mixing's
     // counts drop by up to 9x from one timestep to the next: off; the float64 kernels are built without the jump
     a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 17 : 0;
+    // mixing float32: the ordered part of the scalar transport as parallel passes while their count stays within 24 (12 at the
+    // reference's u_max; ns2d_fast2_impl.h); float64 keeps the reference's ordered sweep
+    a.transport_iter = (a.kind == 1 && sizeof(real) == 4) ? 24 : 0;
     // slow-mode landing guard: the constants of the grids the reference's defaults construct are built in (computed by
     // beacon_amd/stoprule.py, checked by tests/test_oracle.py); any other grid: bcn_set_slow_mode_bound, else BCN_CONV_GUARD alone
     static const struct { int nx, ny, kind; double cx, cut[2], cl[2]; } kBuiltin[] = {
@@ -173,6 +176,7 @@ struct NS2DEnv : bcn_env_s {
     if (!strcmp(name, "plan_overshoot") && value >= 0 && value <= 64) { a.plan_overshoot = value; return BCN_OK; }
     if (!strcmp(name, "verify_conv")) { a.verify_conv = value ? 1 : 0; return BCN_OK; }
     if (!strcmp(name, "spec_start") && value >= 0 && value <= 17) { a.spec_start = value; return BCN_OK; }
+    if (!strcmp(name, "transport_iter") && value >= 0 && value <= 64) { a.transport_iter = value; return BCN_OK; }
     if (!strcmp(name, "sched_tail") && value >= 0 && value <= 1024) { host.sched_tail = value; return BCN_OK; }
     if (!strcmp(name, "generic_threads") && (value == 0 || value == 256 || value == 1024)) { host.generic_nt = value; return BCN_OK; }
     return bcn_env_s::set_option(name, value);

@@ -74,6 +74,8 @@ struct NS2DArgs {
   // slow-mode landing guard of conv_plan 3 (ns2d_fast_impl.h, scripts/weighted_norm_bound.py): log2 of two eigenvalue cutoffs of the
   // Jacobi matrix and, per cutoff, the bound C_L >= 1 on the growth of the reference norm over any number of sweeps within the span
   // of the modes above it -- properties of the grid (nx, ny, kind, cx), set by the host (bcn_set_slow_mode_bound); +inf: none
+  int transport_iter = 0;   // mixing, float32, two-rows-per-lane kernel: the ordered part of the scalar transport as at most this many
+                            // parallel passes (ns2d_fast2_impl.h; bcn_set_option "transport_iter"); 0 = the reference's ordered sweep
   float slow_l2lc[2] = {0.f, 0.f};
   float slow_cl[2] = {__builtin_inff(), __builtin_inff()};
 };

@@ -738,6 +738,8 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
     if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(3)
     // ---- transport: explicit part of every cell, then the ordered part by one wave ------------
+    constexpr bool PARX = KIND == 1 && GF == 0 && std::is_same<real, float>::value;
+    bool par_done = false;
     if constexpr (GF != 0) {
       // Fields in the global scratch: column by column, west to east.  A cell reads the OLD value of its east and north
       // neighbours, so a column can be written as soon as it is computed: its readers are the column to its west (this lane,
@@ -790,11 +792,97 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
           for (int k = 0; k < RW; k++) if (a == 0 || act1) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
       }
+      if constexpr (PARX) {
+        // The ordered part S' = A + aW S'(i-1,j) + aS S'(i,j-1) (mixing.py:478-497: the in-place sweep reads the NEW west and south
+        // values) is a lower-triangular system (I - L) S' = A, and the reference's sweep is its forward substitution: nx + ny/2
+        // dependent steps that one wave walks while seven wait (24 k of a timestep's 143 k cycles).  mixing's scalar is passive and
+        // barely diffusive (Pe = 1e4): |aW| + |aS| <= 2 dt (1 / (Pe dx^2) + u_max / (2 dx)) = 0.204, so the Neumann series
+        // S' = sum_m L^m A converges by a factor rho = max(|aW| + |aS|) per term, and one term is ONE parallel pass of all eight
+        // waves over their cells -- two fmas per cell, the strip's last column exchanged as in the Jacobi sweeps.  rho is measured
+        // in every timestep; M = the number of terms that leaves rho^(M+1) <= 2^-27 (7e-9 of a scalar in [0, 1]: below float32's
+        // rounding of the sweep itself) is 12 at rho = 0.2; where M would exceed A.transport_iter (velocities far above u_max, or
+        // the option set to 0) the ordered sweep below runs instead.  float32 only: float64 keeps the reference's order.
+        // (A is read back from T in LDS in every pass and the coefficients are formed here, behind the explicit part, not in it:
+        // the kernel is at its register limit, and 3 x 2 RW more live values through the explicit part tripled its spills.)
+        if (A.transport_iter > 0) {
+          real aw[2][RW], as[2][RW], X[2][RW];
+          real rho_l = 0;
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+              const int c = (i0 + k) * SY + j0 + a;
+              const bool on = active && (a == 0 || act1);
+              aw[a][k] = on ? dt * A.ksc * rdx2 + (real(0.5) * dt * rdx) * Ul[c] : real(0);
+              as[a][k] = on ? dt * A.ksc * rdy2 + (real(0.5) * dt * rdy) * Vl[c] : real(0);
+              rho_l = __builtin_fmaxf((float)rho_l, (float)(bcn_abs(aw[a][k]) + bcn_abs(as[a][k])));
+            }
+          const real rw63 = wave_max_lane63<real>(rho_l);
+          if (lane == 63) errp[w] = rw63;
+          __syncthreads();   // (also: every thread's A is in T)
+          const real rho = read_lane(row16_max<real>(errp[lane & 15]), 15);
+          // rho^(M+1) <= 2^-27  <=>  M + 1 >= 27 / -log2(rho)
+          const float need = (rho > real(0)) ? 27.f / -__log2f((float)rho) : 0.f;
+          const int M = (rho < real(0.9)) ? __builtin_amdgcn_readfirstlane((int)need) : 1 << 20;   // (ceil(need) - 1 <= (int)need)
+          par_done = M <= A.transport_iter;
+          if (par_done) {
+            // the ghost column i = 0 and the ghost row j = 0 are boundary values, not unknowns: their terms belong to A
+            if (w == 0 && active) {
+              Tl[i0 * SY + j0] += aw[0][0] * Tl[0 * SY + j0];
+              if (act1) Tl[i0 * SY + j0 + 1] += aw[1][0] * Tl[0 * SY + j0 + 1];
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int k = 0; k < RW; k++) Tl[(i0 + k) * SY + j0] += as[0][k] * Tl[(i0 + k) * SY + 0];
+            }
+            real Ak[2][RW];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+              for (int k = 0; k < RW; k++) { Ak[a][k] = Tl[(i0 + k) * SY + j0 + a]; X[a][k] = Ak[a][k]; }   // (own cells: program order)
+            // one pass SRC -> DST, every cell from the previous pass's values (two register sets: no value is copied, every fma of a
+            // pass is independent of the others -- an in-place sweep in the reference's order converges in as many passes by the
+            // same bound and needs no second set, but its 3 x RW dependent instructions ran 2 x longer than these 4 x RW independent ones)
+            real Y[2][RW];
+            auto pass = [&](const real (&SRC)[2][RW], real (&DST)[2][RW]) {
+              ex(xb, w, 1, 0)[lane] = SRC[0][RW - 1];
+              ex(xb, w, 1, 1)[lane] = SRC[1][RW - 1];
+              __syncthreads();
+              const real hw0 = (w > 0) ? ex(xb, w - 1, 1, 0)[lane] : real(0), hw1 = (w > 0) ? ex(xb, w - 1, 1, 1)[lane] : real(0);
+              xb ^= 1;
+              // the strip's first column -- the only one that needs the halo -- last: the LDS read is in flight behind the others
+#pragma unroll
+              for (int kk = 1; kk <= RW; kk++) {
+                const int k = kk < RW ? kk : 0;
+                const real s0 = bcn_dpp::from_below(real(0), SRC[1][k]);   // lane 0: the ghost row, folded into A above
+                DST[0][k] = as[0][k] * s0 + (aw[0][k] * (k ? SRC[0][k ? k - 1 : 0] : hw0) + Ak[0][k]);
+                DST[1][k] = as[1][k] * SRC[0][k] + (aw[1][k] * (k ? SRC[1][k ? k - 1 : 0] : hw1) + Ak[1][k]);
+                if (kk == RW - 1) __builtin_amdgcn_sched_barrier(0);
+              }
+            };
+            int m = 0;
+            for (; m + 2 <= M; m += 2) { pass(X, Y); pass(Y, X); }
+            if (m < M) {
+              pass(X, Y);
+#pragma unroll
+              for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int k = 0; k < RW; k++) X[a][k] = Y[a][k];
+            }
+            if (active) {
+#pragma unroll
+              for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int k = 0; k < RW; k++) if (a == 0 || act1) Tl[(i0 + k) * SY + j0 + a] = X[a][k];
+            }
+          }
+        }
+      }
     }
     __syncthreads();
     if (GF) asm volatile("" : "+v"(j0));
     BCN_PH(4)
-    if (w == 0) {
+    if (w == 0 && !par_done) {
       if constexpr (std::is_same<real, float>::value && GF == 0)
         transport_chain2_f32<NX, NY>(Tl, Ul, Vl, sink, dt * A.ksc * rdx2, real(0.5) * dt * rdx, dt * A.ksc * rdy2, real(0.5) * dt * rdy);
       else

@@ -255,6 +255,13 @@ BCN_API int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t repl
  *                 which the residual is already below the landing guard (log2(1.035) / the previous solve's decay per sweep);
  *                 the landing behind them is verified like any other (plan 3: above 1.035 tol, else the solve is
  *                 repeated without the guess).  BCN_F32 rayleigh only; ignored by BCN_F64 handles, off for mixing
+ *   "transport_iter" 0..64 (mixing, BCN_F32, 64 < ny <= 128): the ordered part of the scalar transport -- mixing.py:478-497 sweeps the
+ *                 array in place, so a cell reads the NEW values of its west and south neighbours: S' = A + aW S'(i-1,j) + aS S'(i,j-1),
+ *                 a lower-triangular system -- as the Neumann series sum_m L^m A, one parallel pass of every wave per term, M terms with
+ *                 rho^(M+1) <= 2^-27, rho = max(|aW| + |aS|) measured in every timestep (0.2 at the reference's u_max: M = 12; 7e-9 of
+ *                 a scalar in [0, 1], below the rounding of the sweep itself).  The option is the largest M allowed (default 24); where
+ *                 the measured rho needs more, and with 0, the ordered sweep of the reference runs (one wave, nx + ny/2 dependent steps).
+ *                 BCN_F64 always runs the ordered sweep
  *   "sched_tail"  short chunks that end a step of the ticket scheduler (0 = default 6; see bcn_set_sched)
  *   "generic_threads" 256 / 1024: workgroup size of the generic 2D kernel (0 = chosen by grid size)
  *   "cells_per_thread" (1D envs) 1, 2, 4, 8 cells per thread (0 = chosen from grid and batch); "one_wave" (1D envs) 0 / 1:

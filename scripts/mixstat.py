@@ -10,7 +10,11 @@ if defs:
 from beacon_amd import vec as V
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-env = V.VecMixing(512, "cuda:0", dtype); env.reset()
+opts = dict(a.split("=") for a in sys.argv[3:] if "=" in a)
+env = V.VecMixing(512, "cuda:0", dtype)
+for k_, v_ in opts.items():
+    env.set_option(k_, int(v_))
+env.reset()
 ai = torch.as_tensor(np.random.default_rng(7).integers(0, 4, (8, 512)), dtype=torch.int32, device="cuda:0")
 for k in range(2):
     env.step(ai[k % 8])

@@ -1771,6 +1771,42 @@ def test_env1d_float64_bit_identical_to_oracle():
     env.close()
 
 
+def test_mixing_parallel_transport_passes_match_the_ordered_sweep():
+    """float32 mixing solves the ordered part of the scalar transport -- the reference's in-place sweep reads the NEW west and south
+    values (mixing.py:478-497): a lower-triangular system -- by its Neumann series, one parallel pass of all waves per term, as many
+    terms as leave rho^(M+1) <= 2^-27 (ns2d_fast2_impl.h; option transport_iter = the most passes allowed, 0 = the ordered sweep).
+    Over a full action step with four different lid actions: velocities, pressure and sweep counts are the SAME BITS (the scalar is
+    passive), the scalar agrees with the ordered sweep to 2e-6 (measured 8e-7 after 250 timesteps: float32 rounding of two
+    different summation orders; the truncation is 7e-9 per timestep) and stays as close to the float64 oracle; with fewer passes
+    allowed than the measured rho needs (transport_iter = 3) the kernel takes the ordered sweep itself: the same bits."""
+    acts = np.array([0, 1, 2, 3, 1, 3])
+    out = {}
+    for ti in (0, 24, 3):
+        env = V.VecMixing(6, DEV, "f32")
+        env.set_option("transport_iter", ti)
+        env.reset()
+        obs, rwd, _, _, _ = env.step(acts)
+        env.step(acts[::-1].copy())
+        env.check_status()
+        assert env.kernel_name.startswith("ns2d_fast2")
+        out[ti] = (env.get_state().clone(), env.sweeps.clone(), env.obs.clone(), env.rwd.clone())
+        env.close()
+    for k in (0, 1, 2):
+        assert torch.equal(out[0][0][:, k], out[24][0][:, k])          # u, v, p
+    assert torch.equal(out[0][1], out[24][1])
+    d = (out[0][0][:, 3] - out[24][0][:, 3]).abs().max().item()
+    assert 0.0 < d <= 2e-6, d                                          # the passes did run, and agree
+    assert maxdiff(out[0][2].cpu().numpy(), out[24][2].cpu().numpy()) <= 2e-6 and maxdiff(out[0][3].cpu().numpy(), out[24][3].cpu().numpy()) <= 2e-6
+    for a, b in zip(out[0], out[3]):
+        assert torch.equal(a, b)                                       # too few passes allowed: the ordered sweep, bit for bit
+    o = O.mixing()
+    o.reset()
+    o.step(int(acts[0]))
+    o.step(int(acts[-1]))
+    d_par, d_ord = maxdiff(dev2ref(out[24][0])[0][3], o.st[3]), maxdiff(dev2ref(out[0][0])[0][3], o.st[3])
+    assert d_par <= d_ord + 2e-6 and d_par <= 4 * F32["mix_bench"]["C"], (d_par, d_ord)   # (two action steps: 500 timesteps)
+
+
 def test_sloshing_packed_float32_kernel_matches_the_unpacked_one_and_the_oracle():
     """float32 sloshing at the reference's grid runs sloshing_step_pk_k (one wave, two cells per v_pk instruction, fluxes per face,
     walls as selects); option one_wave = 2 selects the kernel it replaces.  40 action steps with random actions from the packaged
