@@ -808,7 +808,7 @@ def main():
                                       "a landing below it is repeated under the lower-bound plan: every stop sweep is the reference's.  "
                                       "Within the slow modes of the Jacobi matrix the growth is far smaller (beacon_amd/stoprule.py), which "
                                       "lowers the landing threshold to min(1.035, C_L (1 + 2 e)^2) tol, e from |d_1|^2 and the last evaluated sweep",
-                         "slow_mode_bound": [list(x) for x in env.slow_mode_bound()],
+                         "slow_mode_bound": [list(x) for x in env.slow_mode_bound()] if hasattr(env, "lib") else [],   # (the CPU stub has no library)
                          "unverified_landings_last_step": int(cyc[:, 2].sum()), "repeated_solves_last_step": int(cyc[:, 3].sum()),
                          "solves_last_step": int(B * env.ndt_act)}
         if strong is not None:
