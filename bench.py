@@ -569,6 +569,7 @@ def main():
         --no-overlap as a blocking collective between two steps."""
         for k in range(W):
             senv.step(acts[k], scattered=True)
+            _ = env.sweeps.clone()                      # (the timed loop's own small allocation, so that the caching allocator has it)
         sync()
         if after_warmup is not None:
             after_warmup()
@@ -587,6 +588,9 @@ def main():
             else:
                 with torch.cuda.stream(consumer):
                     p_.wait()
+        import gc
+        gc.collect()
+        gc.disable()                                    # no collector pause inside the K timed steps (20 ms in one of this round's runs)
         t0 = time.perf_counter()
         for k in range(K):
             if use_ev:
@@ -608,6 +612,7 @@ def main():
             deliver(pend)
         sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         env.check_status()
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist.is_initialized():

@@ -8,7 +8,7 @@ N_CU, CLK = 256, 2.4e9
 
 
 def kname(full):
-    m = re.search(r"(ns2d_\w+|\w+_step_k|\w+_kernel)(<[^>]*>)?", full)
+    m = re.search(r"(ns2d_\w+|\w+_step_k|\w+_step_pk_k|\w+_kernel)(<[^>]*>)?", full)
     return (m.group(1) + (m.group(2) or "")) if m else None
 
 
