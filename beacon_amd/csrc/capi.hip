@@ -96,11 +96,13 @@ struct NS2DEnv : bcn_env_s {
     // the landing test of plans 2 / 3 rests on a bound (BCN_CONV_GUARD, bcn_common.h) that holds for grids with no side below 48
     // cells -- every grid the reference can construct (nx = 50 L, ny = 50 H, L, H >= 1); smaller ones: the proven plan
     if (!guard_holds()) a.conv_plan = 1;
-    // rayleigh float32: a solve opens with double sweeps up to 6/8 of the previous timestep's count.  The landing must find the
-    // residual above BCN_CONV_GUARD * tol (ns2d_fast_impl.h: that proves that no skipped sweep passed) or the solve is repeated
-    // without the guess -- measured on the bench workload, repeats per step of 102 400 solves / cycles per sweep: 7/8 27 252 / 916,
-    // 6/8 2 021 / 818, 5/8 205 / 827, 4/8 5 / 837, off 0 / 888 (the unverified rule of round 3 landed at 7/8: 740).  mixing's
-    // counts drop by up to 9x from one timestep to the next: off; the float64 kernels are built without the jump
+    // rayleigh float32: a solve opens with unevaluated double sweeps up to 15/16 of the previous timestep's count minus the stretch
+    // in front of the stop where the residual is already below the landing guard (spec_start 17: ns2d_fast_impl.h); the landing
+    // must find the residual above the guard or the solve is repeated without the guess.  Measured on the bench workload, repeats
+    // per step of 102 400 solves / cycles per sweep -- with the global guard alone and a fixed fraction: 7/8 27 252 / 916,
+    // 6/8 2 021 / 818, 5/8 205 / 827, 4/8 5 / 837, off 0 / 888; with the slow-mode guard: 6/8 789, the zone-aware opening 219 / 778
+    // (the unverified rule of round 3 at 7/8: 750).  mixing's counts drop by up to 9x from one timestep to the next: off; the
+    // float64 kernels are built without the opening
     a.spec_start = (a.kind == 0 && sizeof(real) == 4) ? 17 : 0;
     // mixing float32: the ordered part of the scalar transport as parallel passes while their count stays within 24 (12 at the
     // reference's u_max; ns2d_fast2_impl.h); float64 keeps the reference's ordered sweep

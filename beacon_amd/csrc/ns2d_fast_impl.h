@@ -719,7 +719,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     real phA[R], phB[R];
     bool finalB;
     // tolL: what a LANDING evaluation -- the first one behind skipped sweeps -- must exceed for the skip to be verified.  Plan 3:
-    // BCN_CONV_GUARD * tol, which PROVES that no skipped sweep passed (bcn_common.h); the plan aims its landings above it.
+    // BCN_CONV_GUARD * tol, which PROVES that no skipped sweep passed (bcn_common.h), or less where the slow-mode constants of the
+    // grid allow (tolL below, beacon_amd/stoprule.py); the plan aims its landings above it.
     // Plan 2: tol itself (only a landing that passes is noticed: the unguarded rule of round 2).
     const real tolL0 = (A.conv_plan == 3) ? A.tol * real(BCN_CONV_GUARD) : A.tol;
     const float l2tol_u = __log2f((float)A.tol * 1.02f), l2tol_w = __log2f((float)tolL0 * 1.003f);
