@@ -1464,7 +1464,7 @@ def test_burgers_nx512_vs_oracle_and_mirror():
     # the registers) against the one-wave kernel it replaces (option one_wave = 2) and the float64 oracle over 30 action steps.
     # Measured (scripts/burgers_pk_diff.py): the two kernels differ in the last bit of some fused multiply-adds, 2e-7 after 5
     # steps, 3.6e-6 after 25-40; both sit at the SAME distance from the oracle (5.6e-7 after one step, 3.8e-5 after 30)
-    for nx in (512, 256):
+    for nx in (512, 256, 500, 200):     # (500: the reference's own grid, 200: four cells per lane -- the packed kernel with per-lane masks)
         B = 6
         envs = []
         for ow in (1, 2):
