@@ -19,8 +19,13 @@ no side is shorter than 50 cells): 1.0301 at most, whatever the aspect ratio of 
 -- the boundary layers of two walls interact -- reach 1.041 (20x40, Dirichlet top); the library runs those under the proven plan 1
 (capi.hip).  tests/test_oracle.py::test_weighted_norm_growth_bound_is_below_the_kernels_guard checks three grids.
 
+The same quantity restricted to the SLOW modes of J (|lambda| >= 0.9 / 0.8) is what the kernels' second, much lower landing
+threshold rests on (1.0002 / 1.0057 on 128x64 against 1.030 here): beacon_amd/stoprule.py has the derivation and computes the
+per-grid constants; `--slow` prints them.
+
     python scripts/weighted_norm_bound.py                 the table of DESIGN.md (about two minutes)
-    python scripts/weighted_norm_bound.py NX NY KIND      one grid (KIND 0 rayleigh, 1 mixing); optional CX (default 0.25)"""
+    python scripts/weighted_norm_bound.py NX NY KIND      one grid (KIND 0 rayleigh, 1 mixing); optional CX (default 0.25)
+    python scripts/weighted_norm_bound.py --slow NX NY KIND [CX]    the slow-mode constants of that grid (beacon_amd/stoprule.py)"""
 import sys
 
 import numpy as np
@@ -79,6 +84,15 @@ def bound(nx, ny, kind, cx=0.25, ms=(1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32,
 
 
 def main(argv):
+    if argv and argv[0] == "--slow":
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from beacon_amd import stoprule
+        nx, ny, kind = int(argv[1]), int(argv[2]), int(argv[3])
+        cx = float(argv[4]) if len(argv) > 4 else 0.25
+        for lc, b in stoprule.bounds(nx, ny, kind, cx, cache=False):
+            print("%dx%d kind %d cx %.3f: within the modes |lambda| >= %.2f the norm grows by at most %.5f (global guard %.3f)" % (nx, ny, kind, cx, lc, b, GUARD))
+        return 0
     if len(argv) >= 3:
         nx, ny, kind = int(argv[0]), int(argv[1]), int(argv[2])
         cx = float(argv[3]) if len(argv) > 3 else 0.25
