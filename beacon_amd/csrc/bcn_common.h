@@ -80,6 +80,7 @@ struct bcn_env_s {
   virtual int get_slow_mode_bound(double*, double*) const { return 0; }
   virtual int get_counters(uint64_t* host, hipStream_t) { memset(host, 0, (size_t)batch * 4 * sizeof(uint64_t)); return BCN_OK; }   // only the 2D register-resident kernels schedule
   virtual const char* kernel_name() const = 0;
+  virtual void note_kernel(const char*) {}   // 1D envs: the step kernel the launcher chose (packed or general)
   int32_t* stp = nullptr;  // device int32[B]
 };
 

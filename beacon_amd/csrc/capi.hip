@@ -10,6 +10,8 @@
 #include "env1d.h"
 #include "ns2d.h"
 
+thread_local const char* bcn_env1d_launched = nullptr;   // env1d.h: set by the 1D launchers
+
 static thread_local char g_err[512] = "";
 
 // default visibility: the on-demand kernel plugins (csrc/jit/ns2d_jit.hip) report through the library's error buffer
@@ -342,6 +344,7 @@ struct Env1D : bcn_env_s {
     return copy_state(const_cast<void*>(buf), is_device, s, false);
   }
   const char* kernel_name() const override { return kname; }
+  void note_kernel(const char* n) override { kname = n; }
   void set_mask(const uint8_t* m) override { a.mask = m; }
   int set_option(const char* name, int value) override {
     if (!strcmp(name, "cells_per_thread") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { a.force_k = value; return BCN_OK; }
@@ -547,8 +550,11 @@ int bcn_burgers_step(bcn_env_t h, const void* actions_dev, const void* noise_dev
                      uint8_t* done_dev, uint8_t* trunc_dev, int32_t* status_dev, void* stream) {
   BCN_CHECK_KIND(h, BCN_BURGERS);
   DeviceGuard g(h->device);
-  return BCN_1D_CALL(h, burgers_launch_step, actions_dev, noise_dev, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+  bcn_env1d_launched = nullptr;
+  const int rc_ = BCN_1D_CALL(h, burgers_launch_step, actions_dev, noise_dev, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
                      status_dev);
+  h->note_kernel(bcn_env1d_launched ? bcn_env1d_launched : "burgers_step_k");
+  return rc_;
 }
 
 int bcn_shkadov_create(const bcn_shkadov_cfg* c, int batch, int dtype, int device, bcn_env_t* out) {
@@ -597,8 +603,11 @@ int bcn_sloshing_step(bcn_env_t h, const void* actions_dev, void* obs_dev, void*
                       uint8_t* trunc_dev, int32_t* status_dev, void* stream) {
   BCN_CHECK_KIND(h, BCN_SLOSHING);
   DeviceGuard g(h->device);
-  return BCN_1D_CALL(h, sloshing_launch_step, actions_dev, nullptr, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
+  bcn_env1d_launched = nullptr;
+  const int rc_ = BCN_1D_CALL(h, sloshing_launch_step, actions_dev, nullptr, nullptr, obs_dev, rwd_dev, done_dev, trunc_dev,
                      status_dev);
+  h->note_kernel(bcn_env1d_launched ? bcn_env1d_launched : "sloshing_step_k");
+  return rc_;
 }
 
 // ---- common ----------------------------------------------------------------------------------

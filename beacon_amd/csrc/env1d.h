@@ -68,6 +68,8 @@ __device__ __forceinline__ real bcn_device_noise(const Env1DArgs<real>& A, int b
   return (real(2) * r - real(1)) * A.nsigma;
 }
 
+// name of the step kernel the last *_launch_step of this thread dispatched when it is not the env's general one (else nullptr)
+extern thread_local const char* bcn_env1d_launched;
 template <typename real> int burgers_launch_step(const Env1DArgs<real>& a, int batch, hipStream_t s);
 template <typename real> int burgers_launch_reset(const Env1DArgs<real>& a, int batch, hipStream_t s);
 template <typename real> int shkadov_launch_step(const Env1DArgs<real>& a, int batch, hipStream_t s);

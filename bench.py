@@ -142,7 +142,8 @@ def committed_profile(kernel_name, key, dtype="f32", grid_tag=None):
             real = "<double" if dtype == "f64" else "<float"
             if grid_tag and "<" in name and grid_tag not in name:
                 continue                         # another grid's instantiation of the same kernel template
-            if name.startswith(kernel_name) and (real in name or "<" not in name) and key in c and "reset" not in name:
+            typed = "<float" in name or "<double" in name           # (burgers_step_pk_k<8> carries no element type: float32 only)
+            if name.startswith(kernel_name) and (real in name or not typed) and key in c and "reset" not in name:
                 best = {"value": c[key], "source": os.path.basename(f), "sweeps_per_dispatch": c.get("sweeps_per_dispatch")}
     return best
 
@@ -302,10 +303,23 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
         return s.elapsed_time(e) / (reps * n)
 
     def line(name, env, ms, alg_bytes, extra=None):
+        # the state of these kernels is on chip for the whole action step: what binds them is vector-instruction issue.  The
+        # instruction count per dispatch is the committed profile's (SQ_INSTS_VALU of profiles/*_summary.json for this kernel);
+        # the SURVEY 8d bytes over the time stay beside it as `hbm_effective` (above the HBM peak where nothing goes to HBM)
+        dt = "f64" if env.tdtype == torch.float64 else "f32"
+        hbm_eff = {"achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "SURVEY 8d algorithmic bytes / time: not the binding resource"}
+        prof = committed_profile(env.kernel_name, "SQ_INSTS_VALU", dt)
+        if prof is not None:
+            ach = prof["value"] / (ms * 1e-3)
+            roof = {"bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instructions/s",
+                    "frac": ach / VALU_ISSUE_PEAK, "instructions": "SQ_INSTS_VALU per dispatch of " + prof["source"],
+                    "instructions_measured_in_this_run": False, "hbm_effective": hbm_eff}
+        else:
+            roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instructions/s", "frac": None,
+                    "note": "no committed profile of this kernel", "hbm_effective": hbm_eff}
         d = {"workload": name, "value": env.batch / (ms * 1e-3), "unit": "env steps/s", "ms_per_launch": ms,
-             "kernel": env.kernel_name, "dtype": "f64" if env.tdtype == torch.float64 else "f32",
-             "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+             "kernel": env.kernel_name, "dtype": dt, "roofline": roof}
         d.update(extra or {})
         out.append(d)
 
