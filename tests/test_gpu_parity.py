@@ -1464,7 +1464,10 @@ def test_burgers_nx512_vs_oracle_and_mirror():
     # the registers) against the one-wave kernel it replaces (option one_wave = 2) and the float64 oracle over 30 action steps.
     # Measured (scripts/burgers_pk_diff.py): the two kernels differ in the last bit of some fused multiply-adds, 2e-7 after 5
     # steps, 3.6e-6 after 25-40; both sit at the SAME distance from the oracle (5.6e-7 after one step, 3.8e-5 after 30)
-    for nx in (512, 256, 500, 200):     # (500: the reference's own grid, 200: four cells per lane -- the packed kernel with per-lane masks)
+    # (500: the reference's own grid; 200, 130: four cells per lane; 497: the last cell is a lane's FIRST cell, its copy comes from the
+    # lane below -- the packed kernel with per-lane masks)
+    # (coarse grids under random forcing blow up after 15-30 action steps, in the oracle too: eight steps there)
+    for nx in (512, 256, 500, 200, 497, 130):
         B = 6
         envs = []
         for ow in (1, 2):
@@ -1475,7 +1478,7 @@ def test_burgers_nx512_vs_oracle_and_mirror():
         ors = [O.burgers(nx=nx) for _ in range(B)]
         for o in ors:
             o.reset()
-        for k in range(30):
+        for k in range(30 if nx >= 256 else 8):
             a, nz = rng.uniform(-1, 1, B), rng.uniform(-0.1, 0.1, B)
             outs = [e.step(a, nz) for e in envs]
             st = [e.get_state() for e in envs]
@@ -1813,6 +1816,23 @@ def test_sloshing_packed_float32_kernel_matches_the_unpacked_one_and_the_oracle(
     developed state: measured (scripts/burgers_pk_diff.py) both kernels sit at the same distance from the float64 oracle -- h 2e-7
     after one step, 3e-6 after 40; q 6e-7 / 1.2e-5 -- and differ from each other by as much; the right-hand-side arrays are flux
     differences times 1 / dx = 80 (values up to 25: an ulp of the flux is 2e-6, 1.5e-4 after the division), so their bound is 2e-3."""
+    # other tank lengths (nx = 160, 240: the far wall in another lane and cell), from rest, against the unpacked kernel
+    rng = np.random.default_rng(5)
+    for L in (2.0, 3.0):
+        pair = []
+        for ow in (1, 2):
+            e = V.VecSloshing(4, DEV, "f32", None, L=L)
+            e.set_option("one_wave", ow)
+            e.reset()
+            pair.append(e)
+        for k in range(12):
+            a = rng.uniform(-1, 1, 4)
+            outs = [e.step(a) for e in pair]
+            st = [e.get_state().double().cpu().numpy() for e in pair]
+            assert maxdiff(st[0][:, :2], st[1][:, :2]) <= 4e-5 and maxdiff(st[0][:, 2:], st[1][:, 2:]) <= 2e-3, (L, k)
+            assert maxdiff(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) <= 1e-6
+        for e in pair:
+            e.close()
     init = E.packaged_init("sloshing")
     rng = np.random.default_rng(3)
     B = 6
