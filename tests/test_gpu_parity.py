@@ -1548,6 +1548,41 @@ def test_shkadov_vs_golden(tag, kw, init, dtype):
     env.close()
 
 
+@pytest.mark.parametrize("L0,n_jets", [(10.0, 1), (30.0, 2), (150.0, 5)])
+def test_shkadov_packed_step_variants_match_the_scalar_step_and_the_oracle(L0, n_jets):
+    """The packed float32 timestep of shkadov_step_k has four wave variants (interior; holding the first thread; the last
+    thread; both, where the array is ONE wave) besides the jet flag.  nx = 200: one wave with both ends; nx = 350: not a
+    multiple of 4, the scalar step runs whatever the option (the control of this test); nx = 1100, the reference's default:
+    five waves with cells, three idle.  Against option one_wave = 2 (the scalar step in the same exchange layout) and the
+    float64 oracle, from the flat film with inlet noise and random jets, ten action steps."""
+    rng = np.random.default_rng(17)
+    B = 3
+    envs = []
+    for ow in (1, 2):
+        e = V.VecShkadov(B, DEV, "f32", None, L0=L0, n_jets=n_jets, jet_pos=L0)
+        e.set_option("one_wave", ow)
+        e.reset()
+        envs.append(e)
+    o = O.shkadov(L0=L0, n_jets=n_jets, jet_pos=L0, init_fields=np.ones((2, envs[0].nx)))    # the flat film
+    o.rand_init = False
+    o.reset()
+    nx, ndt = envs[0].nx, envs[0].ndt_act
+    for k in range(10):
+        a, nz = rng.uniform(-1, 1, (B, n_jets)), rng.uniform(-5e-4, 5e-4, (B, ndt))
+        outs = [e.step(a, nz) for e in envs]
+        st = [e.get_state().double().cpu().numpy() for e in envs]
+        assert maxdiff(st[0][:, :2], st[1][:, :2]) <= 5e-6 and maxdiff(st[0][:, 2:], st[1][:, 2:]) <= 5e-4, (nx, k)
+        assert maxdiff(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy()) <= 5e-6
+        ob, rw, dn, tr, _ = o.step(a[0].tolist(), nz[0])
+        # h within the bound of the reference episodes; q -- the flux, which random full-amplitude jets drive five times harder than
+        # those episodes do -- no further from the oracle than the scalar step is (measured: 1.4e-4 after seven steps, both)
+        assert maxdiff(st[0][0, 0], o.h) <= shkadov_tol("f32", k + 1), (nx, k)
+        assert maxdiff(st[0][0, 1], o.q) <= max(1.5 * maxdiff(st[1][0, 1], o.q), shkadov_tol("f32", k + 1)), (nx, k)
+        assert maxdiff(outs[0][0][0].double().cpu().numpy(), ob) <= 5 * shkadov_tol("f32", k + 1)
+    for e in envs:
+        e.close()
+
+
 # measured (round 4): see the assertions of the two tests below
 # developed N = 4096 film, float32 against the float64 oracle: observations 4.6e-6 at the third step, rewards 1.3e-9; wave
 # amplitude of the 1024 films (below); episode statistics of float32 against float64 over 64 replicas: mean of the returns
