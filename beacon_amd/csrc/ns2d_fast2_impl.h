@@ -854,8 +854,11 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
 #pragma unroll
               for (int kk = 1; kk <= RW; kk++) {
                 const int k = kk < RW ? kk : 0;
-                const real s0 = bcn_dpp::from_below(real(0), SRC[1][k]);   // lane 0: the ghost row, folded into A above
-                DST[0][k] = as[0][k] * s0 + (aw[0][k] * (k ? SRC[0][k ? k - 1 : 0] : hw0) + Ak[0][k]);
+                // the south term of the lower row as ONE v_fmac_f32_dpp: t += aS * (upper row of the lane below); lane 0 has no lane
+                // below and keeps t -- its ghost row is folded into A above.  (SRC was written a pass ago: no DPP hazard to wait for.)
+                float t = aw[0][k] * (k ? SRC[0][k ? k - 1 : 0] : hw0) + Ak[0][k];
+                asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(SRC[1][k]), "v"(as[0][k]));
+                DST[0][k] = t;
                 DST[1][k] = as[1][k] * SRC[0][k] + (aw[1][k] * (k ? SRC[1][k ? k - 1 : 0] : hw1) + Ak[1][k]);
                 if (kk == RW - 1) __builtin_amdgcn_sched_barrier(0);
               }
