@@ -773,6 +773,7 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
       }
     } else {
       real Ac[2][RW];
+      real rho_l = 0;   // PARX: max |aW| + |aS| over the thread's cells (the coefficients of the new west / south values, below)
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -784,14 +785,19 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
                             (uE * real(0.5) * (TE + T0) - uW * real(0.5) * T0) * rdx -
                             (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
           Ac[a][k] = T0 + dt * expl;
+          if constexpr (PARX) {
+            if (active && (a == 0 || act1))
+              rho_l = __builtin_fmaxf((float)rho_l, (float)(bcn_abs(dt * A.ksc * rdx2 + (real(0.5) * dt * rdx) * uW) +
+                                                            bcn_abs(dt * A.ksc * rdy2 + (real(0.5) * dt * rdy) * vS)));
+          }
         }
-      __syncthreads();
-      if (active) {
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int k = 0; k < RW; k++) if (a == 0 || act1) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
+      if constexpr (PARX) {
+        if (A.transport_iter > 0) {
+          const real rw63 = wave_max_lane63<real>(rho_l);
+          if (lane == 63) errp[w] = rw63;
+        }
       }
+      __syncthreads();
       if constexpr (PARX) {
         // The ordered part S' = A + aW S'(i-1,j) + aS S'(i,j-1) (mixing.py:478-497: the in-place sweep reads the NEW west and south
         // values) is a lower-triangular system (I - L) S' = A, and the reference's sweep is its forward substitution: nx + ny/2
@@ -802,44 +808,39 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
         // in every timestep; M = the number of terms that leaves rho^(M+1) <= 2^-27 (7e-9 of a scalar in [0, 1]: below float32's
         // rounding of the sweep itself) is 12 at rho = 0.2; where M would exceed A.transport_iter (velocities far above u_max, or
         // the option set to 0) the ordered sweep below runs instead.  float32 only: float64 keeps the reference's order.
-        // (A is read back from T in LDS in every pass and the coefficients are formed here, behind the explicit part, not in it:
-        // the kernel is at its register limit, and 3 x 2 RW more live values through the explicit part tripled its spills.)
         if (A.transport_iter > 0) {
           real aw[2][RW], as[2][RW], X[2][RW];
-          real rho_l = 0;
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int k = 0; k < RW; k++) {
-              const int c = (i0 + k) * SY + j0 + a;
-              const bool on = active && (a == 0 || act1);
-              aw[a][k] = on ? dt * A.ksc * rdx2 + (real(0.5) * dt * rdx) * Ul[c] : real(0);
-              as[a][k] = on ? dt * A.ksc * rdy2 + (real(0.5) * dt * rdy) * Vl[c] : real(0);
-              rho_l = __builtin_fmaxf((float)rho_l, (float)(bcn_abs(aw[a][k]) + bcn_abs(as[a][k])));
-            }
-          const real rw63 = wave_max_lane63<real>(rho_l);
-          if (lane == 63) errp[w] = rw63;
-          __syncthreads();   // (also: every thread's A is in T)
           const real rho = read_lane(row16_max<real>(errp[lane & 15]), 15);
           // rho^(M+1) <= 2^-27  <=>  M + 1 >= 27 / -log2(rho)
           const float need = (rho > real(0)) ? 27.f / -__log2f((float)rho) : 0.f;
+#ifdef BCN_DBG_PASSES   // diagnostic build (scripts/mixstat.py -DBCN_DBG_PASSES=n): a fixed number of passes, to time one (wrong results)
+          const int M = BCN_DBG_PASSES + 0 * (int)need;
+#else
           const int M = (rho < real(0.9)) ? __builtin_amdgcn_readfirstlane((int)need) : 1 << 20;   // (ceil(need) - 1 <= (int)need)
+#endif
           par_done = M <= A.transport_iter;
           if (par_done) {
-            // the ghost column i = 0 and the ghost row j = 0 are boundary values, not unknowns: their terms belong to A
-            if (w == 0 && active) {
-              Tl[i0 * SY + j0] += aw[0][0] * Tl[0 * SY + j0];
-              if (act1) Tl[i0 * SY + j0 + 1] += aw[1][0] * Tl[0 * SY + j0 + 1];
-            }
-            if (lane == 0) {
-#pragma unroll
-              for (int k = 0; k < RW; k++) Tl[(i0 + k) * SY + j0] += as[0][k] * Tl[(i0 + k) * SY + 0];
-            }
-            real Ak[2][RW];
+            // the coefficients, formed here and not in the explicit part (2 x 2 RW more live values through it tripled the spills)
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
-              for (int k = 0; k < RW; k++) { Ak[a][k] = Tl[(i0 + k) * SY + j0 + a]; X[a][k] = Ak[a][k]; }   // (own cells: program order)
+              for (int k = 0; k < RW; k++) {
+                const int c = (i0 + k) * SY + j0 + a;
+                const bool on = active && (a == 0 || act1);
+                aw[a][k] = on ? dt * A.ksc * rdx2 + (real(0.5) * dt * rdx) * Ul[c] : real(0);
+                as[a][k] = on ? dt * A.ksc * rdy2 + (real(0.5) * dt * rdy) * Vl[c] : real(0);
+              }
+            // the ghost column i = 0 and the ghost row j = 0 are boundary values, not unknowns: their terms belong to A
+            if (w == 0) { Ac[0][0] += aw[0][0] * Tl[0 * SY + j0]; Ac[1][0] += aw[1][0] * Tl[0 * SY + j0 + 1]; }
+            if (lane == 0) {
+#pragma unroll
+              for (int k = 0; k < RW; k++) Ac[0][k] += as[0][k] * Tl[(i0 + k) * SY + 0];
+            }
+            real (&Ak)[2][RW] = Ac;   // A stays in the registers of the explicit part
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+              for (int k = 0; k < RW; k++) X[a][k] = Ak[a][k];
             // one pass SRC -> DST, every cell from the previous pass's values (two register sets: no value is copied, every fma of a
             // pass is independent of the others -- an in-place sweep in the reference's order converges in as many passes by the
             // same bound and needs no second set, but its 3 x RW dependent instructions ran 2 x longer than these 4 x RW independent ones)
@@ -880,6 +881,12 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
             }
           }
         }
+      }
+      if (!par_done && active) {   // the ordered sweep below reads A from T
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int k = 0; k < RW; k++) if (a == 0 || act1) Tl[(i0 + k) * SY + j0 + a] = Ac[a][k];
       }
     }
     __syncthreads();
