@@ -417,7 +417,10 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
           }
         }
         // the pending column k-1 (not the strip's first one) goes to memory now: the wave-wide loads of that column have
-        // returned (their data went into column k-2 .. k), and the loads in flight are of columns >= k+2
+        // returned (their data went into column k-2 .. k), and the loads in flight are of columns >= k+2.  The fence keeps
+        // hipcc from moving a store in front of a load of rows j0 - 1 / j0 + 2 of that column (other lanes' cells: per thread the
+        // addresses differ, see the transport's explicit part below)
+        asm volatile("" ::: "memory");
         if (k >= 2) {
           if (active) {
             const int c = (i - 1) * SY + j0;
@@ -760,6 +763,13 @@ __device__ __forceinline__ void fast2_body(const NS2DArgs<real>& A, char* smem, 
                             (vN * real(0.5) * (TN + T0) - vS * real(0.5) * T0) * rdy;
           Ak[a] = T0 + dt * expl;
         }
+        // The stores below must stay BEHIND both rows' loads above: the upper row's TN is row j0 + 2 -- the lower row of the
+        // lane above, which that lane overwrites with its Ak[0] here.  Per thread the two addresses differ, so nothing but
+        // this fence tells hipcc so.  With even ny the two rows leave as ONE 16-byte store that needs Ak[1] and so follows the
+        // loads by data dependence; odd ny splits it (the last lane has no upper row) and hipcc then moved the Ak[0] store in
+        // front of the upper row's loads: every upper row behind a strip's first column read the NEW value of its north
+        // neighbour (50x75 float64, round 5: T wrong by 2e-2 after one timestep).
+        asm volatile("" ::: "memory");
         if (k == 0) { A0[0] = Ak[0]; A0[1] = Ak[1]; }
         else if (active) {
           Tl[(i0 + k) * SY + j0] = Ak[0];
