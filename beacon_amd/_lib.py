@@ -79,6 +79,8 @@ SIGNATURES = {
     "bcn_dtype": (C.c_int, [vp]),
     "bcn_n_obs": (C.c_int, [vp]),
     "bcn_n_act": (C.c_int, [vp]),
+    "bcn_ndt_act": (C.c_int, [vp]),
+    "bcn_device": (C.c_int, [vp]),
     "bcn_state_elems": (C.c_size_t, [vp]),
     "bcn_get_state": (C.c_int, [vp, vp, C.c_int, vp]),
     "bcn_set_state": (C.c_int, [vp, vp, C.c_int, vp]),

@@ -82,6 +82,7 @@ struct bcn_env_s {
   virtual const char* kernel_name() const = 0;
   virtual void note_kernel(const char*) {}   // 1D envs: the step kernel the launcher chose (packed or general)
   int32_t* stp = nullptr;  // device int32[B]
+  int ndt_act = 0;         // timesteps per action step (rows of the callers' sweeps / noise buffers: bcn_ndt_act)
 };
 
 // device allocation tracked per handle

@@ -252,7 +252,7 @@ int make_rayleigh(const bcn_rayleigh_cfg* c, int batch, int dtype, int device, b
   a.ksc = (real)(1.0 / sqrt(c->pr * c->ra));
   a.Tc = (real)c->Tc; a.Th = (real)c->Th; a.C = (real)c->C;
   a.rwd_scale = (real)(1.0 / (0.5 * c->dy * c->nx));
-  e->n_obs = a.n_obs; e->n_act = c->n_sgts;
+  e->n_obs = a.n_obs; e->n_act = c->n_sgts; e->ndt_act = a.ndt_act;
   int rc = e->init();
   if (rc) { delete e; return rc; }
   *out = e;
@@ -274,7 +274,7 @@ int make_mixing(const bcn_mixing_cfg* c, int batch, int dtype, int device, bcn_e
   a.kmom = (real)(1.0 / c->re);
   a.ksc = (real)(1.0 / c->pe);
   a.u_max = (real)c->u_max; a.ref_c = (real)c->ref_c; a.C0 = (real)c->C0;
-  e->n_obs = a.n_obs; e->n_act = 1;
+  e->n_obs = a.n_obs; e->n_act = 1; e->ndt_act = a.ndt_act;
   int rc = e->init();
   if (rc) { delete e; return rc; }
   *out = e;
@@ -364,7 +364,7 @@ int make_burgers(const bcn_burgers_cfg* c, int batch, int dtype, int device, bcn
   a.ctrl_pos = c->ctrl_pos; a.n_obs_pts = c->n_obs_pts;
   a.u_target = (real)c->u_target; a.amp = (real)c->amp;
   a.dx = (real)c->dx; a.rdx = (real)(1.0 / c->dx); a.dt = (real)c->dt;
-  e->n_obs = c->n_obs_pts; e->n_act = 1;
+  e->n_obs = c->n_obs_pts; e->n_act = 1; e->ndt_act = a.ndt_act;
   int rc = e->init(1);
   if (rc) { delete e; return rc; }
   *out = e;
@@ -386,7 +386,7 @@ int make_shkadov(const bcn_shkadov_cfg* c, int batch, int dtype, int device, bcn
   a.jet_amp = (real)c->jet_amp; a.eps = (real)c->eps; a.h_blow = (real)c->h_blow;
   a.blowup_rwd = (real)c->blowup_rwd;
   a.dx = (real)c->dx; a.rdx = (real)(1.0 / c->dx); a.dt = (real)c->dt;
-  e->n_obs = a.n_obs; e->n_act = c->n_jets;
+  e->n_obs = a.n_obs; e->n_act = c->n_jets; e->ndt_act = a.ndt_act;
   int rc = e->init(c->n_jets);
   if (rc) { delete e; return rc; }
   *out = e;
@@ -405,7 +405,7 @@ int make_sloshing(const bcn_sloshing_cfg* c, int batch, int dtype, int device, b
   a.n_interp = c->n_interp;
   a.g = (real)c->g; a.amp = (real)c->amp; a.alpha = (real)c->alpha;
   a.dx = (real)c->dx; a.rdx = (real)(1.0 / c->dx); a.dt = (real)c->dt;
-  e->n_obs = a.n_obs; e->n_act = 1;
+  e->n_obs = a.n_obs; e->n_act = 1; e->ndt_act = a.ndt_act;
   int rc = e->init(1);
   if (rc) { delete e; return rc; }
   *out = e;
@@ -616,6 +616,8 @@ int bcn_batch(bcn_env_t h) { return h ? h->batch : 0; }
 int bcn_dtype(bcn_env_t h) { return h ? h->dtype : -1; }
 int bcn_n_obs(bcn_env_t h) { return h ? h->n_obs : 0; }
 int bcn_n_act(bcn_env_t h) { return h ? h->n_act : 0; }
+int bcn_ndt_act(bcn_env_t h) { return h ? h->ndt_act : 0; }
+int bcn_device(bcn_env_t h) { return h ? h->device : -1; }
 size_t bcn_state_elems(bcn_env_t h) { return h ? h->state_elems() : 0; }
 
 int bcn_get_state(bcn_env_t h, void* buf, int is_device, void* stream) {

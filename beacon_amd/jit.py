@@ -27,6 +27,11 @@ import warnings
 
 from . import build as _build
 
+class JitWarning(UserWarning):
+    """Every warning of this module: a plugin that could not be built / loaded / checked, or that failed its self-check.
+    tests/conftest.py turns the category into an error, so a refused plugin is a red test, not a line in a log."""
+
+
 JIT_DIR = os.path.join(_build.PKG, "_jit")
 JIT_SRC = os.path.join(_build.CSRC, "jit", "ns2d_jit.hip")
 LDS_BYTES = 160 * 1024
@@ -179,40 +184,73 @@ def compare_with_generic(make_env, kind, f64, ndt=6, batch=3):
     return ok, "; ".join(rep)
 
 
+def _read(path):
+    try:
+        with open(path) as fh:
+            return fh.read()
+    except OSError:
+        return None
+
+
+def _verdict_on_disk(p, tag):
+    """True / False from the marker files beside the shared object, None where there is none for this device + runtime."""
+    bad = _read(p.path + ".bad")
+    if bad is not None:
+        return False, bad.strip()[:300]
+    ok = _read(p.path + ".ok")
+    if ok is not None and ok.split("\n")[0].strip() == tag:
+        return True, ok
+    return None, ""
+
+
 def verify(p, make_env, kind, f64):
-    """Sets p.verified (True / False) -- from the marker files next to the shared object, or by running compare_with_generic()."""
+    """Sets p.verified (True / False) -- from the marker files next to the shared object, or by running compare_with_generic().
+    One process per plugin runs the comparison: the N ranks of a fresh node queue on `<plugin>.vlock` and all but the first find
+    the first one's verdict on disk when the lock comes to them."""
     global CHECKING
-    okf, badf = p.path + ".ok", p.path + ".bad"
-    if os.path.exists(badf):
-        p.verified = False
-        warnings.warn("beacon_amd.jit: %s failed its self-check earlier (%s); the generic kernel stays selected"
-                      % (os.path.basename(p.path), open(badf).read().strip()[:300]))
-        return
     tag = _runtime_tag()
+
+    def settle(v, text):
+        p.verified = v
+        if not v:
+            warnings.warn("beacon_amd.jit: %s failed its self-check earlier (%s); the generic kernel stays selected"
+                          % (os.path.basename(p.path), text), JitWarning)
+
+    v, text = _verdict_on_disk(p, tag)
+    if v is not None:
+        return settle(v, text)
+    lock = None
     try:
-        if os.path.exists(okf) and open(okf).read().split("\n")[0].strip() == tag:
-            p.verified = True
+        lock = open(p.path + ".vlock", "w")
+        fcntl.flock(lock, fcntl.LOCK_EX)
+    except OSError:
+        lock = None                 # read-only package directory: every process checks for itself
+    try:
+        v, text = _verdict_on_disk(p, tag)       # written by another rank while this one waited
+        if v is not None:
+            return settle(v, text)
+        CHECKING = True
+        try:
+            ok, rep = compare_with_generic(make_env, kind, f64)
+        except Exception as e:      # noqa: BLE001 -- could not run (out of memory, ...): no verdict, no plugin for this env
+            warnings.warn("beacon_amd.jit: the self-check of %s could not run (%s: %s); the generic kernel stays selected for this env"
+                          % (os.path.basename(p.path), type(e).__name__, e), JitWarning)
             return
-    except OSError:
-        pass
-    CHECKING = True
-    try:
-        ok, rep = compare_with_generic(make_env, kind, f64)
-    except Exception as e:      # noqa: BLE001 -- could not run (out of memory, ...): no verdict, no plugin for this env
-        warnings.warn("beacon_amd.jit: the self-check of %s could not run (%s: %s); the generic kernel stays selected for this env"
-                      % (os.path.basename(p.path), type(e).__name__, e))
-        return
+        finally:
+            CHECKING = False
+        p.verified, p.report = bool(ok), rep
+        try:
+            with open(p.path + (".ok" if ok else ".bad"), "w") as fh:
+                fh.write("%s\n%s\n" % (tag, rep))
+        except OSError:
+            pass                    # read-only package directory: the verdict holds for this process
     finally:
-        CHECKING = False
-    p.verified, p.report = bool(ok), rep
-    try:
-        with open(okf if ok else badf, "w") as fh:
-            fh.write("%s\n%s\n" % (tag, rep))
-    except OSError:
-        pass                    # read-only package directory: the verdict holds for this process
+        if lock is not None:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+            lock.close()
     if not ok:
         warnings.warn("beacon_amd.jit: the register-resident kernel %s DISAGREES with the generic kernel on its self-check (%s); "
-                      "it is not used: the generic kernel stays selected" % (os.path.basename(p.path), rep))
+                      "it is not used: the generic kernel stays selected" % (os.path.basename(p.path), rep), JitWarning)
 
 
 def selftest(device="cuda:0", verbose=False):
@@ -290,7 +328,7 @@ def build_plugin(nx, ny, f64, kind, verbose=False, extra_defs=None):
         # a read-only package directory, a full disk or a compiler error: the env keeps the generic kernel
         # (still on the GPU, only slower) instead of failing in its constructor
         warnings.warn("beacon_amd.jit: no register-resident kernel for %dx%d (%s); the generic kernel stays selected"
-                      % (nx, ny, e))
+                      % (nx, ny, e), JitWarning)
         try:
             os.remove(tmp)
         except OSError:
@@ -320,7 +358,7 @@ def plugin_for(nx, ny, f64, kind, extra_defs=None):
         try:
             p = Plugin(path) if path else None
         except (OSError, AttributeError) as e:        # a truncated or foreign shared object in the cache
-            warnings.warn("beacon_amd.jit: cannot load %s (%s); the generic kernel stays selected" % (path, e))
+            warnings.warn("beacon_amd.jit: cannot load %s (%s); the generic kernel stays selected" % (path, e), JitWarning)
             p = None
         if p is not None and p.lds > LDS_BYTES:
             p = None
@@ -334,7 +372,9 @@ TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 6
               (50, 70, False, 0), (60, 120, False, 0), (100, 110, False, 1), (150, 50, True, 0), (110, 65, False, 0),
               (100, 105, False, 1), (50, 70, True, 0), (50, 150, False, 0), (50, 150, True, 0), (64, 200, False, 0),
               (100, 200, False, 1), (50, 145, False, 0), (50, 149, True, 0), (100, 130, False, 1),
-              (300, 50, False, 0), (200, 100, False, 1), (53, 150, False, 0), (106, 200, False, 1)]
+              (300, 50, False, 0), (200, 100, False, 1), (53, 150, False, 0), (106, 200, False, 1),
+              # float64, two rows per lane, ODD ny, strips of unequal width (9 / 5, 10 / 7): the class of the wrong kernel of round 5
+              (50, 75, True, 0), (57, 107, True, 0), (100, 105, True, 1)]
 
 
 def fuzz_grids(seed=5):
@@ -364,12 +404,59 @@ def fuzz_grids(seed=5):
     return out
 
 
+def _grid(L, H, kind):
+    n = 50 if kind == 0 else 100
+    return int(n * L), int(n * H)
+
+
+def fuzz_cases(seed=6):
+    """fuzz_grids() (default constructor arguments) plus 15 draws that cover what those 22 never met (the
+    wrong 50x75 float64 kernel was the only float64 two-rows-per-lane grid with ODD ny anyone had built, and it ran with
+    n_sgts = 5, ra = 5e4): per kernel family and precision -- (rows per lane, float64) -- an odd-ny quota (one row 2 + 2, two rows
+    rayleigh 2 + 2 and mixing 2 + 1, the hybrid 1 + 1 each), every case with the reference's OTHER constructor arguments drawn as well: rayleigh n_sgts in 1..12
+    and ra in [8e3, 2e5] (rayleigh.py:20-27), mixing re in [50, 400], pe in [1e3, 1e5], side in [0.3, 0.7], C0 in [0.5, 2]
+    (mixing.py:20-34).  Returns (L, H, f64, kind, kwargs)."""
+    import numpy as np
+    out = [(L, H, f64, kind, {}) for L, H, f64, kind in fuzz_grids()]
+    rng = np.random.default_rng(seed)
+    quota = {(1, False, 0): 2, (1, True, 0): 2, (2, False, 0): 2, (2, True, 0): 2, (2, False, 1): 2, (2, True, 1): 1,
+             (4, False, 0): 1, (4, True, 0): 1, (4, False, 1): 1, (4, True, 1): 1}
+    while any(quota.values()):
+        kind = int(rng.integers(0, 2))
+        f64 = bool(rng.integers(0, 2))
+        if kind == 0:
+            L = round(float(rng.uniform(1.0, 4.5)), 2)
+            H = round(float(rng.uniform(1.0, 1.3) if rng.integers(0, 2) else rng.uniform(1.0, 3.2)), 2)
+            kw = dict(n_sgts=int(rng.integers(1, 13)), ra=float(round(10.0 ** rng.uniform(np.log10(8e3), np.log10(2e5)), -2)))
+        else:
+            L, H = round(float(rng.uniform(1.0, 1.7)), 2), round(float(rng.uniform(1.0, 2.3)), 2)
+            kw = dict(re=float(round(rng.uniform(50, 400), 0)), pe=float(round(10.0 ** rng.uniform(3, 5), -1)),
+                      side=round(float(rng.uniform(0.3, 0.7)), 2), C0=round(float(rng.uniform(0.5, 2.0)), 2))
+        nx, ny = _grid(L, H, kind)
+        m = choose(nx, ny, f64, kind)
+        if m is None or ny % 2 == 0 or nx * ny > 30000 or not quota.get((m["rows"], f64, kind)):
+            continue
+        quota[(m["rows"], f64, kind)] -= 1
+        out.append((L, H, f64, kind, kw))
+    return out
+
+
 def fuzz_grid_keys():
-    return [((int(50 * L), int(50 * H)) if kind == 0 else (int(100 * L), int(100 * H))) + (f64, kind) for L, H, f64, kind in fuzz_grids()]
+    return [_grid(L, H, kind) + (f64, kind) for L, H, f64, kind, _ in fuzz_cases()]
 
 
 # plugins built with extra -D flags: the deliberately wrong kernel of the self-check's own test
 EXTRA_BUILDS = [((75, 50, True, 0), {"BCN_JIT_BREAK": 1})]
+
+
+def _bounds_job(cell):
+    from . import stoprule
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=2):
+            stoprule.bounds(*cell)
+    except ImportError:
+        stoprule.bounds(*cell)
 
 
 def prebuild(grids=None, verbose=False):
@@ -386,13 +473,15 @@ def prebuild(grids=None, verbose=False):
     from . import stoprule
     cells = [(nx, ny, kind, 0.25) for (nx, ny, f64, kind), _ in todo]
     if grids is None:
-        for L, H, f64, kind in fuzz_grids():
-            n = 50 if kind == 0 else 100
-            dx, dy = float(L / int(n * L)), float(H / int(n * H))
-            cells.append((int(n * L), int(n * H), kind, dy * dy / (2.0 * (dx * dx + dy * dy))))
-    for nx, ny, kind, cx in sorted(set(cells)):
-        if ny <= 128 and min(nx, ny) >= 48:
-            stoprule.bounds(nx, ny, kind, cx)
+        for L, H, f64, kind, _ in fuzz_cases():
+            nx, ny = _grid(L, H, kind)
+            dx, dy = float(L / nx), float(H / ny)
+            cells.append((nx, ny, kind, dy * dy / (2.0 * (dx * dx + dy * dy))))
+    want = [c for c in sorted(set(cells)) if c[1] <= 128 and min(c[0], c[1]) >= 48 and not os.path.exists(stoprule._cache_file(*c))]
+    if want:      # ~10 s of dense algebra per grid: a few grids at a time, two BLAS threads each
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=int(os.environ.get("BEACON_JIT_JOBS", "4"))) as ex:
+            list(ex.map(_bounds_job, want))
     if os.path.isdir(JIT_DIR):
         # drop the plugins of older source states of THESE grids (same name up to the hash); plugins that users compiled
         # on demand for other grids stay (a stale one is merely unused: build_plugin() compiles the current hash next to it)

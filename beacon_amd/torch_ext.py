@@ -104,6 +104,12 @@ def load():
             path = None
     if path is None:
         return None
-    torch.ops.load_library(path)
+    try:
+        torch.ops.load_library(path)
+    except (OSError, RuntimeError) as e:     # a truncated library, one built against another torch or another C ABI
+        import warnings
+        warnings.warn("beacon_amd: the torch extension %s could not be loaded (%s); the ctypes binding of the same C ABI is used"
+                      % (os.path.basename(path), str(e).splitlines()[0] if str(e) else type(e).__name__))
+        return None
     _LOADED = torch.ops.beacon
     return _LOADED

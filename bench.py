@@ -327,14 +327,15 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
     z = {"fields": head_init}
     W = head_warm
 
-    def headline_variant(name, dtype, opts, note):
+    def headline_variant(name, dtype, opts, note, nrep=None, extra=None):
         """The headline workload itself (same initial state, same warm-up and timed action stream) with other solver
-        options / in float64: ms per step over the same `steps` steps."""
-        env = V.VecRayleigh(head_acts.shape[1], dev, dtype, z["fields"], L=head_LH[0], H=head_LH[1])
+        options / in float64 / on its first `nrep` replicas only: ms per step over the same `steps` steps."""
+        nrep = head_acts.shape[1] if nrep is None else nrep
+        env = V.VecRayleigh(nrep, dev, dtype, z["fields"], L=head_LH[0], H=head_LH[1])
         for k_, v_ in opts.items():
             env.set_option(k_, v_)
         env.reset()
-        acts = torch.as_tensor(head_acts, dtype=env.tdtype, device=dev)
+        acts = torch.as_tensor(head_acts[:, :nrep], dtype=env.tdtype, device=dev)
         k = [0]
 
         sw = []
@@ -348,10 +349,11 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
         c = env.get_counters()
         esz = 4 if dtype == "f32" else 8
         alg = float(np.mean([algorithmic_bytes(env.nx, env.ny, x.cpu().numpy(), esz) for x in sw]))
-        line(name, env, ms, alg,
-             {"mean_jacobi_sweeps_per_timestep": float(np.mean([x.float().mean().item() for x in sw])), "steps": n,
-              "options": opts, "note": note,
-              "unverified_landings_last_step": int(c[:, 2].sum()), "repeated_solves_last_step": int(c[:, 3].sum())})
+        d = {"mean_jacobi_sweeps_per_timestep": float(np.mean([x.float().mean().item() for x in sw])), "steps": n,
+             "options": opts, "note": note, "replicas": nrep,
+             "unverified_landings_last_step": int(c[:, 2].sum()), "repeated_solves_last_step": int(c[:, 3].sum())}
+        d.update(extra or {})
+        line(name, env, ms, alg, d)
         env.close()
 
     ai = torch.as_tensor(rng.integers(0, 4, (8, 512)), dtype=torch.int32, device=dev)
@@ -367,6 +369,18 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
                          {"conv_plan": 2, "spec_start": 7},
                          "the extrapolating plan trusting a failing landing -- not proven (the reference's norm can grow by 1.030 "
                          "between sweeps): what the verification of plan 3 costs")
+
+    def leg_strong_scaling_shards():
+        # what ONE rank of a 2 / 4 / 8-GPU strong-scaling run of the headline executes: the first 512 / N replicas of the same
+        # action stream on this GPU (replicas are independent: a rank's shard does not know the others exist).  Below one
+        # replica per CU a step cannot get shorter -- a replica is a serial chain on one CU -- so these lines are what the
+        # top-level `scaling_prediction` is computed from
+        full = head_acts.shape[1]
+        for n_gpus in (2, 4, 8):
+            if full % n_gpus == 0 and full // n_gpus >= 1:
+                headline_variant("headline workload, the %d replicas of one rank of a %d-GPU strong-scaling run" % (full // n_gpus, n_gpus),
+                                 "f32", {}, "replicas 0..%d of the headline's action stream, same steps" % (full // n_gpus - 1),
+                                 nrep=full // n_gpus, extra={"strong_scaling_shard_of": n_gpus})
 
     def leg_headline_f64():
         # rayleigh 128x64 float64 (the reference's arithmetic), B=512, the headline's own steps
@@ -459,7 +473,7 @@ def secondary_lines(dev, head_acts, head_warm, head_init, head_LH, quick_steps=4
     def leg_lorenz():
         out.append(lorenz_line())
 
-    for leg in (leg_stop_rules, leg_headline_f64, leg_mixing_f32, leg_mixing_f64, leg_tall_grid, leg_burgers, leg_shkadov,
+    for leg in (leg_stop_rules, leg_strong_scaling_shards, leg_headline_f64, leg_mixing_f32, leg_mixing_f64, leg_tall_grid, leg_burgers, leg_shkadov,
                 leg_sloshing, leg_lorenz):
         try:      # one failing configuration must not cost the others (nor the headline: main() guards this whole function too)
             leg()
@@ -857,6 +871,32 @@ def main():
             sec += guarded("secondary configurations", lambda: secondary_lines(dev, acts_np, W, init, (L, H))) or []
         if sec:
             out["secondary"] = sec
+        # Predicted 1 / 2 / 4 / 8-GPU values from what THIS GPU measured (no hardware curve is claimed): replicas are independent,
+        # a rank of an N-GPU run executes exactly one of the lines above plus the packed gather, whose cost per step is the
+        # difference between the one-rank-over-RCCL line and the plain loop.  A later SCALE run can be checked against this.
+        if world == 1 and sec:
+            t1 = 1e3 * elapsed / K
+            gath = [d for d in sec if "through the N > 1 path" in d.get("workload", "") and "side stream" in d.get("workload", "")
+                    and "ms_per_step" in d]
+            over = max(0.0, gath[0]["ms_per_step"] - t1) if gath else None
+            shards = {d["strong_scaling_shard_of"]: d for d in sec if "strong_scaling_shard_of" in d and "ms_per_launch" in d}
+            pred = {"gather_overhead_ms_per_step": over,
+                    "note": "weak: N x (512 replicas per GPU, this run's step + the one-rank gather overhead); strong: 512 replicas "
+                            "over N GPUs, ms = the 512 / N-replica line of `secondary` + the same overhead; efficiency = value / "
+                            "(N x this run's value).  Strong scaling leaves 256 - 512 / N of a GPU's 256 CUs without a replica "
+                            "(one workgroup per replica, a replica is a serial chain): its efficiency is bounded by that, not by "
+                            "communication", "weak": [], "strong": []}
+            o = over or 0.0
+            for n_ in (1, 2, 4, 8):
+                tw = t1 + (o if n_ > 1 else 0.0)
+                pred["weak"].append({"n_gpus": n_, "ms_per_step": tw, "value": n_ * Bg / (tw * 1e-3), "efficiency": t1 / tw})
+                if n_ == 1:
+                    pred["strong"].append({"n_gpus": 1, "replicas_per_gpu": Bg, "ms_per_step": t1, "value": Bg / (t1 * 1e-3), "efficiency": 1.0})
+                elif n_ in shards:
+                    ts_ = shards[n_]["ms_per_launch"] + o
+                    pred["strong"].append({"n_gpus": n_, "replicas_per_gpu": shards[n_]["replicas"], "ms_per_step": ts_,
+                                           "value": Bg / (ts_ * 1e-3), "efficiency": (Bg / (ts_ * 1e-3)) / (n_ * Bg / (t1 * 1e-3))})
+            out["scaling_prediction"] = pred
         if world == 1 and not args.no_secondary and not args.stub:
             for d in sec:      # what the proof costs: the unverified rule of rounds 3-4 next to the headline
                 if d.get("options") == {"conv_plan": 2, "spec_start": 7} and d.get("dtype") == args.dtype:

@@ -170,6 +170,8 @@ BCN_API int bcn_batch(bcn_env_t h);
 BCN_API int bcn_dtype(bcn_env_t h);
 BCN_API int bcn_n_obs(bcn_env_t h);       /* observation length per replica */
 BCN_API int bcn_n_act(bcn_env_t h);       /* action length per replica */
+BCN_API int bcn_ndt_act(bcn_env_t h);     /* timesteps per action step: rows of sweeps_dev [B][ndt_act] and of shkadov's noise_dev */
+BCN_API int bcn_device(bcn_env_t h);      /* HIP device index the handle was created on (every *_dev pointer must live there) */
 /* Solver state of all replicas, the equivalent of the env's field attributes (and of
  * dump()/load(), rayleigh.py:344-362): elements per replica, then copy out / in.  Layout per
  * replica: rayleigh/mixing [4][ny+2][nx+2] = u,v,p,S; burgers [3][nx] = u,up,upp;
@@ -244,7 +246,14 @@ BCN_API int bcn_set_noise(bcn_env_t h, double sigma, uint64_t seed, int64_t repl
  *                     counted ([2]) and the solve repeated under plan 1 (the default of both precisions; grids with a side below 48
  *                     cells, where the bound is larger, take plans 0 / 1 only).  With the grid's slow-mode constants in force
  *                     (bcn_set_slow_mode_bound below; built in for the default grids) the landing threshold drops from 1.035 tol
- *                     to a fraction of a percent above tol late in a solve -- still a proof, and far fewer evaluations;
+ *                     to a fraction of a percent above tol late in a solve -- still a proof, and far fewer evaluations.
+ *                     What "proof" covers: the recurrence d' = J d in EXACT arithmetic, which BCN_F64 follows to 1e-16.  BCN_F32
+ *                     adds rounding of ~eps |phi| per cell and sweep to the increments (0.05 - 0.3 % of tol = 1e-8 on 8192 cells),
+ *                     the size of the slow-mode threshold's distance from tol; the kernels put a 0.1 % margin on that threshold
+ *                     and the float32 default is VERIFIED EMPIRICALLY on top (option "verify_conv": every sweep evaluated next to
+ *                     the plan over whole episodes of the bench workload, no BCN_ST_PLAN: tests/test_gpu_parity.py), not proven;
+ *                     a caller who wants the float32 proof unconditional clears the slow-mode constants
+ *                     (bcn_set_slow_mode_bound(h, 0, ...)): BCN_CONV_GUARD's 3.5 % dwarf the rounding;
  *                 2 = plan 3's extrapolation WITHOUT the verification (round 2's rule: it notices a landing only when the
  *                     landing itself passes, and then only counts it): kept for measurements, never a default
  *   "plan_overshoot" 0..64, TEST HOOK: lengthens every skip of plans 2 / 3 by that many sweeps, so that landings fall behind

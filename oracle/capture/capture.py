@@ -298,6 +298,64 @@ def job_mixing_synth():
     save("mixing_synth", **out)
 
 
+def _ctor_case(out, tag, mod, s, sname, state, action, ndt, nsnap):
+    """`ndt` timesteps of one step() from `state` with stage snapshots of the first `nsnap` timesteps, stored under the prefix `tag`."""
+    for f, a in zip("uvp" + sname, state):
+        if a is not None:
+            getattr(s, f)[:] = a
+    s.ndt_act = ndt
+    for f in "uvp" + sname:
+        out["%s_%s0" % (tag, f)] = getattr(s, f).copy()
+    rec = StageRecorder(mod, sname, nsnap)
+    t0 = time.time()
+    obs, rwd, done, trunc, _ = s.step(action)
+    rec.restore()
+    print(tag, "itp", rec.itp, "%.1fs" % (time.time() - t0), flush=True)
+    out[tag + "_obs"], out[tag + "_rwd"] = obs.copy(), rwd
+    out[tag + "_itp"] = np.array(rec.itp, dtype=np.int64)
+    for f in "uvp" + sname:
+        out["%s_%s" % (tag, f)] = getattr(s, f).copy()
+    for k, v in rec.stacked().items():
+        out["%s_%s" % (tag, k)] = v
+
+
+def job_ctor_args():
+    """The reference's NON-geometric constructor arguments: mixing(re, pe, side, C0) (mixing.py:21-34; u_max =
+    re nu / L scales the lid speed, so re moves the transport's CFL number and pe its diffusion number) and rayleigh(n_sgts, ra)
+    (rayleigh.py:20-27), a few timesteps each from a seeded synthetic state with stage snapshots, plus reset() where side / C0 matter."""
+    out = {}
+    mod, d = load_ref("mixing")
+    for tag, kw, amp, action in (("mix_re50_pe1e3_a0", dict(re=50.0, pe=1.0e3), 0.01, 0),
+                                 ("mix_re50_pe1e3_a3", dict(re=50.0, pe=1.0e3), 0.01, 3),
+                                 ("mix_re200_pe1e5_a1", dict(re=200.0, pe=1.0e5, side=0.3, C0=2.0), 0.02, 1),
+                                 ("mix_re200_pe1e5_a2", dict(re=200.0, pe=1.0e5, side=0.3, C0=2.0), 0.02, 2),
+                                 ("mix_re400_pe2e3_a0", dict(re=400.0, pe=2.0e3, side=0.62, C0=0.5), 0.04, 0)):
+        s = mod.mixing(**kw)
+        obs0, _ = s.reset()
+        out[tag + "_reset_obs"], out[tag + "_reset_C"], out[tag + "_reset_rwd"] = obs0.copy(), s.C.copy(), s.get_rwd()
+        out[tag + "_fparams"] = np.array([s.L, s.H, s.dx, s.dy, s.dt, s.re, s.pe, s.u_max, s.side, s.C0])
+        u, v, p, _ = synth_state_2d(s.nx, s.ny, s.dx, s.dy, 21, amp, False)
+        # (the second action of a parameter set starts from the same state: only its results are kept, and no snapshots)
+        first = tag in ("mix_re50_pe1e3_a0", "mix_re200_pe1e5_a1", "mix_re400_pe2e3_a0")
+        _ctor_case(out, tag, mod, s, "C", (u, v, p, None), np.int64(action), 4, 1 if first else 0)
+        if not first:
+            for suf in ("u0", "v0", "p0", "C0", "reset_obs", "reset_C", "reset_rwd", "fparams"):
+                del out["%s_%s" % (tag, suf)]
+    mod, d = load_ref("rayleigh")
+    for tag, kw, seed in (("ray_sgts5_ra5e4", dict(n_sgts=5, ra=5.0e4), 31), ("ray_sgts12_ra8e3_50x75", dict(n_sgts=12, ra=8.0e3, H=1.5), 32),
+                          ("ray_sgts3_ra2e5", dict(n_sgts=3, ra=2.0e5), 33)):
+        s = mod.rayleigh(init=False, **kw)
+        s.reset_fields()
+        out[tag + "_fparams"] = np.array([s.L, s.H, s.dx, s.dy, s.dt, s.pr, s.ra, s.Tc, s.Th, s.C])
+        out[tag + "_params"] = np.array([s.nx, s.ny, s.n_sgts, s.nx_sgts], dtype=np.int64)
+        u, v, p, T = synth_state_2d(s.nx, s.ny, s.dx, s.dy, seed, 0.02, True)
+        act = np.random.default_rng(seed).uniform(-1.0, 1.0, s.n_sgts)
+        out[tag + "_action"] = act.copy()
+        _ctor_case(out, tag, mod, s, "T", (u, v, p, T), act.tolist(), 5, 2)
+        out[tag + "_a_norm"] = np.array(s.a)
+    save("ctor_args", **out)
+
+
 def s_C0(mod):
     s = mod.mixing()
     s.reset()
@@ -502,6 +560,7 @@ JOBS = {
     "mixing_synth": job_mixing_synth,
     "burgers": job_burgers,
     "shkadov": job_shkadov,
+    "ctor_args": job_ctor_args,
     "sloshing": job_sloshing,
     "lorenz": job_lorenz,
 }

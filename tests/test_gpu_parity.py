@@ -835,6 +835,29 @@ def test_conv_plan_3_repeats_late_stops_under_the_proven_plan(kind):
     assert torch.equal(plan3[0], literal[0]) and torch.equal(plan3[1], literal[1])
 
 
+def test_float32_default_plan_verified_over_a_long_bench_episode():
+    """the float32 default (conv_plan 3 with the slow-mode landing guard) is proven for exact arithmetic; float32
+    rounding of the increments is the size of the guard's distance from tol, so the default is VERIFIED on the bench workload
+    over a long stretch: 16 action steps = 3 200 timesteps x 256 replicas = 819 200 solves with every sweep evaluated next to
+    the plan (verify_conv): no replica may raise BCN_ST_PLAN (a sweep the plan skipped passed the test), none may overflow, and
+    sweep counts and fields must equal the planned run's bit for bit."""
+    def run(verify):
+        env, init, acts = _bench_workload(256, 16, "f32")
+        env.set_option("verify_conv", verify)
+        flags, sw = 0, []
+        for k in range(16):
+            env.step(acts[k])
+            flags |= int(env.status.max())
+            sw.append(env.sweeps.clone())
+        out = (flags, torch.stack(sw), env.get_state().clone(), env.get_counters())
+        env.close()
+        return out
+    planned, verified = run(0), run(1)
+    assert planned[0] == 0 and verified[0] == 0, (planned[0], verified[0])
+    assert torch.equal(planned[1], verified[1]) and torch.equal(planned[2], verified[2])
+    assert int(planned[1].min()) >= 1 and int(planned[1].max()) > 60
+
+
 @pytest.mark.parametrize("kind,dtype", [("rayleigh", "f32"), ("rayleigh", "f64"), ("mixing", "f32")])
 def test_tall_grid_evaluation_plans_never_change_a_result(kind, dtype):
     """ns2d_fast4_impl.h (ny > 128: rayleigh 50x150, mixing 100x200) evaluates the Jacobi residual only where its plan says
@@ -1006,7 +1029,7 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
                                             (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL),
                                             (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5),
                                             (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL), (6.0, 1.0, "f32", 5e-5),
-                                            (1.06, 3.0, "f32", 5e-5)])
+                                            (1.06, 3.0, "f32", 5e-5), (1.0, 1.5, "f64", F64_TOL), (1.14, 2.14, "f64", F64_TOL)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
@@ -1845,6 +1868,120 @@ def test_mixing_parallel_transport_passes_match_the_ordered_sweep():
     assert d_par <= d_ord + 2e-6 and d_par <= 4 * F32["mix_bench"]["C"], (d_par, d_ord)   # (two action steps: 500 timesteps)
 
 
+# ---- the reference's non-geometric constructor arguments on the register-resident kernels -------------------
+# (tag, the tag whose start state / reset() it shares, constructor arguments, action)
+MIX_CTOR = [("mix_re50_pe1e3_a0", "mix_re50_pe1e3_a0", dict(re=50.0, pe=1.0e3), 0),
+            ("mix_re50_pe1e3_a3", "mix_re50_pe1e3_a0", dict(re=50.0, pe=1.0e3), 3),
+            ("mix_re200_pe1e5_a1", "mix_re200_pe1e5_a1", dict(re=200.0, pe=1.0e5, side=0.3, C0=2.0), 1),
+            ("mix_re200_pe1e5_a2", "mix_re200_pe1e5_a1", dict(re=200.0, pe=1.0e5, side=0.3, C0=2.0), 2),
+            ("mix_re400_pe2e3_a0", "mix_re400_pe2e3_a0", dict(re=400.0, pe=2.0e3, side=0.62, C0=0.5), 0)]
+RAY_CTOR = [("ray_sgts5_ra5e4", dict(n_sgts=5, ra=5.0e4)), ("ray_sgts12_ra8e3_50x75", dict(n_sgts=12, ra=8.0e3, H=1.5)),
+            ("ray_sgts3_ra2e5", dict(n_sgts=3, ra=2.0e5))]
+# float32, four / five timesteps from the seeded states of tests/golden/ctor_args.npz (measured maxima in the comment of each test)
+F32["mix_ctor"] = f32tol(1e-6, 1e-6, 4e-6, 2.5e-6, 2.5e-6, 3e-7)
+F32["ray_ctor"] = f32tol(3e-7, 3e-7, 2.5e-6, 2.5e-6, 2.5e-6, 3e-5)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,t0,kw,act", MIX_CTOR, ids=[c[0] for c in MIX_CTOR])
+def test_mixing_constructor_arguments_vs_reference(tag, t0, kw, act, dtype):
+    """mixing(re, pe, side, C0) (mixing.py:21-34) on ns2d_fast2 (set_variant(1)): reset() -- patch side / C0, reward level -- and
+    four timesteps from the seeded state, against what the REFERENCE itself returned (tests/golden/ctor_args.npz): float64 1e-9
+    with its sweep counts (first solve 2472: the lid speed u_max = re nu / L enters through the boundary conditions), float32
+    F32["mix_ctor"] with counts within max(3, 2 %).  re = 200 / 400 double / quadruple the lid speed, and with it the spectral
+    radius the float32 kernel's parallel transport passes are counted from."""
+    g = golden("ctor_args")
+    B = 3
+    env = V.VecMixing(B, DEV, dtype, **kw)
+    env.set_ndt_act(4)
+    assert env.set_variant(1) == 1
+    obs0 = env.reset()
+    obs0 = (obs0[0] if isinstance(obs0, tuple) else obs0).double().cpu().numpy()
+    t = F32["mix_ctor"] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, F64_TOL)
+    st = dev2ref(env.get_state())
+    assert maxdiff(st[0][3], g[t0 + "_reset_C"]) <= (0 if dtype == "f64" else 1e-7)
+    n = 3 * env.nx_obs_pts * env.ny_obs_pts
+    assert maxdiff(obs0[0][-n:], g[t0 + "_reset_obs"][-n:]) <= t["obs"]
+    st0 = np.stack([g["%s_%s0" % (t0, f)] for f in "uvpC"])
+    env.set_state(np.tile(ref_to_dev(st0)[None], (B, 1, 1, 1)))
+    obs, rwd, _, _, _ = env.step(np.full(B, act))
+    env.check_status()
+    assert env.kernel_name.startswith("ns2d_fast2")
+    st, sw = dev2ref(env.get_state()), env.sweeps.cpu().numpy()
+    for b in range(B):
+        for i, F in enumerate("uvpC"):
+            assert maxdiff(st[b][i], g["%s_%s" % (tag, F)]) <= t[F], (b, F)
+        assert maxdiff(obs[b].double().cpu().numpy()[-n:], g[tag + "_obs"][-n:]) <= t["obs"]
+        assert maxdiff(float(rwd[b]), float(g[tag + "_rwd"])) <= t["rwd"]
+        assert np.all(np.abs(sw[b] - g[tag + "_itp"]) <= (1 if dtype == "f64" else np.maximum(3, 0.02 * g[tag + "_itp"]))), (sw[b], g[tag + "_itp"])
+    env.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,kw", RAY_CTOR, ids=[c[0] for c in RAY_CTOR])
+def test_rayleigh_constructor_arguments_vs_reference(tag, kw, dtype):
+    """rayleigh(n_sgts, ra) (rayleigh.py:20-27) on the register-resident kernels (set_variant(1): ns2d_fast at 50x50, ns2d_fast2
+    -- two rows per lane, odd ny, strips of 9 and 5 columns: the wrong kernel of round 5 -- at 50x75): five timesteps from the
+    seeded state against what the REFERENCE returned; 12 and 3 segments on 50 cells leave the last bottom ghosts unwritten."""
+    g = golden("ctor_args")
+    B = 3
+    env = V.VecRayleigh(B, DEV, dtype, None, **kw)
+    env.set_ndt_act(5)
+    assert env.set_variant(1) == 1
+    env.reset()
+    t = F32["ray_ctor"] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, 50 * F64_TOL)
+    st0 = np.stack([g["%s_%s0" % (tag, f)] for f in "uvpT"])
+    env.set_state(np.tile(ref_to_dev(st0)[None], (B, 1, 1, 1)))
+    a = np.tile(g[tag + "_action"][None], (B, 1))
+    obs, rwd, _, _, _ = env.step(a)
+    env.check_status()
+    assert env.kernel_name == ("ns2d_fast2_step" if env.ny > 64 else "ns2d_fast_step")
+    assert maxdiff(env.actions_norm.double().cpu().numpy()[0], g[tag + "_a_norm"]) <= (1e-15 if dtype == "f64" else 1e-7)
+    st, sw = dev2ref(env.get_state()), env.sweeps.cpu().numpy()
+    n = 3 * env.nx_obs_pts * env.ny_obs_pts
+    for b in range(B):
+        for i, F in enumerate("uvpT"):
+            assert maxdiff(st[b][i], g["%s_%s" % (tag, F)]) <= t[F], (b, F)
+        assert maxdiff(obs[b].double().cpu().numpy()[-n:], g[tag + "_obs"][-n:]) <= t["obs"]
+        assert maxdiff(float(rwd[b]), float(g[tag + "_rwd"])) <= t["rwd"]
+        assert np.all(np.abs(sw[b] - g[tag + "_itp"]) <= (1 if dtype == "f64" else np.maximum(3, 0.02 * g[tag + "_itp"]))), (sw[b], g[tag + "_itp"])
+    env.close()
+
+
+@pytest.mark.parametrize("scale,passes", [(45.0, True), (80.0, False)])
+def test_mixing_transport_passes_beyond_twelve_terms_and_the_fallback(scale, passes):
+    """The float32 mixing kernel counts its parallel transport passes from the measured rho = max(|aW| + |aS|) (mixing.py:478-497
+    as a Neumann series; include/beacon_hip.h: "transport_iter").  At the reference's defaults rho = 0.2 -> 12 terms.  Here the
+    seeded velocity field (max |u| + |v| = 0.069) is scaled (a) by 45: rho = 0.31 -> 16 terms -- with at most 12 allowed the kernel
+    falls back to the ordered sweep (same bits as transport_iter 0), with the default 24 the passes run and agree with the ordered
+    sweep and the float64 oracle; (b) by 80: rho = 0.55 -> 31 terms: the default itself falls back -- the bits of the ordered sweep."""
+    g = golden("mixing_synth")
+    st0 = np.stack([g["u0"] * scale, g["v0"] * scale, g["p0"], g["C0"]])
+    out = {}
+    for ti in (0, 12, 24):
+        env = V.VecMixing(4, DEV, "f32")
+        env.set_ndt_act(3)
+        env.set_option("transport_iter", ti)
+        env.reset()
+        env.set_state(np.tile(ref_to_dev(st0)[None], (4, 1, 1, 1)))
+        env.step(np.array([4, 4, 4, 4]))          # walls at rest (mixing.py:233): the seeded field alone sets rho
+        env.check_status()
+        out[ti] = (env.get_state().clone(), env.sweeps.clone())
+        env.close()
+    assert torch.equal(out[12][0], out[0][0]) and torch.equal(out[12][1], out[0][1])      # more than 12 needed: the ordered sweep
+    same = torch.equal(out[24][0], out[0][0])
+    assert same != passes, "rho of this state: the passes %s" % ("did not run" if passes else "ran")
+    o = O.mixing()
+    o.cfg.ndt_act = 3
+    o.reset()
+    o.st[:4] = st0
+    o.step(np.int64(4))
+    ref = dev2ref(out[24][0])[0]
+    assert maxdiff(ref[3], o.st[3]) <= 2.5e-6
+    for i in range(3):
+        assert torch.equal(out[24][0][:, i], out[0][0][:, i])                                # velocities, pressure: the same bits
+
+
 def test_sloshing_packed_float32_kernel_matches_the_unpacked_one_and_the_oracle():
     """float32 sloshing at the reference's grid runs sloshing_step_pk_k (one wave, two cells per v_pk instruction, fluxes per face,
     walls as selects); option one_wave = 2 selects the kernel it replaces.  40 action steps with random actions from the packaged
@@ -2562,26 +2699,46 @@ def test_two_ranks_share_the_gpu_over_gloo(tmp_path):
 # ---- on-demand kernels: first-use self-check ---------------------------------------------
 def _fuzz_ids():
     from beacon_amd import jit
-    return ["%s-%dx%d-%s" % (("rayleigh", "mixing")[k[3]], k[0], k[1], "f64" if k[2] else "f32") for k in jit.fuzz_grid_keys()]
+    return ["%s-%dx%d-%s%s" % (("rayleigh", "mixing")[c[3]], *jit._grid(c[0], c[1], c[3]), "f64" if c[2] else "f32", "-args" if c[4] else "")
+            for c in jit.fuzz_cases()]
 
 
-@pytest.mark.parametrize("idx", range(22), ids=_fuzz_ids() if torch.cuda.is_available() else None)
+@pytest.mark.parametrize("idx", range(37), ids=_fuzz_ids())
 def test_jit_fuzzed_grids_agree_with_the_generic_kernel(idx):
-    """22 random domain sizes (seeded; the reference takes any L, H: rayleigh.py:20-27, mixing.py:20-28) across every
+    """37 random domain sizes (seeded; the reference takes any L, H: rayleigh.py:20-27, mixing.py:20-28) across every
     kernel family -- one / two rows per lane and the hybrid, float32 and float64 -- each through the comparison that guards a
     plugin's first use (beacon_amd/jit.py: six timesteps, plain launch and ticket scheduler, against the generic kernel):
-    float64 1e-9 with sweep counts within 1, float32 2e-4 with counts within max(3, 2 %).  (Promoted from
-    scripts/fuzz_grids.py; the plugins are compiled by __graft_entry__.build().)"""
+    float64 1e-9 with sweep counts within 1, float32 2e-4 with counts within max(3, 2 %).  The last 15 (round 6) have ODD ny
+    in every (family, precision, env) class and draw the reference's other constructor arguments too: n_sgts, ra / re, pe,
+    side, C0.  (The plugins are compiled by __graft_entry__.build().)"""
     from beacon_amd import jit
-    L, H, f64, kind = jit.fuzz_grids()[idx]
+    L, H, f64, kind, kw = jit.fuzz_cases()[idx]
     dt = "f64" if f64 else "f32"
-    mk = (lambda B: V.VecRayleigh(B, DEV, dt, None, L=L, H=H)) if kind == 0 else (lambda B: V.VecMixing(B, DEV, dt, L=L, H=H))
+    mk = (lambda B: V.VecRayleigh(B, DEV, dt, None, L=L, H=H, **kw)) if kind == 0 else (lambda B: V.VecMixing(B, DEV, dt, L=L, H=H, **kw))
     env = mk(2)             # the constructor itself runs the self-check of a plugin that has no verdict yet
     p = getattr(env, "_plugin", None)
     assert p is not None and p.verified is True, "no verified plugin for this grid"
     env.close()
     ok, rep = jit.compare_with_generic(mk, kind, f64)       # and once more here, whatever the marker files say
     assert ok, rep
+
+
+def test_jit_no_plugin_of_the_test_grids_was_refused():
+    """Every grid of jit.TEST_GRIDS and of the fuzz list: its plugin is built, attaches, and carries a PASSED self-check on
+    this box (a refused one is already an error through JitWarning; this is the inventory -- no `.bad` marker anywhere in
+    beacon_amd/_jit/ except the deliberately broken plugin's own, which its test removes)."""
+    from beacon_amd import jit
+    for nx, ny, f64, kind in jit.TEST_GRIDS + [k for k in jit.fuzz_grid_keys() if k not in jit.TEST_GRIDS]:
+        n = 50.0 if kind == 0 else 100.0
+        L, H = [c / n if int(n * (c / n)) == c else (c + 0.5) / n for c in (nx, ny)]
+        dt = "f64" if f64 else "f32"
+        env = V.VecRayleigh(2, DEV, dt, None, L=L, H=H) if kind == 0 else V.VecMixing(2, DEV, dt, L=L, H=H)
+        assert (env.nx, env.ny) == (nx, ny)
+        p = getattr(env, "_plugin", None)
+        assert p is not None and p.verified is True, "%dx%d %s kind %d: no verified plugin" % (nx, ny, dt, kind)
+        env.close()
+    bad = [f for f in os.listdir(jit.JIT_DIR) if f.endswith(".bad")]
+    assert not bad, bad
 
 
 def test_jit_self_check_refuses_a_broken_plugin_and_keeps_the_generic_kernel():

@@ -237,6 +237,84 @@ def test_mixing_synthetic_all_actions():
             assert np.array_equal(getattr(e, f), g["a%d_%s" % (act, F)])
 
 
+# (tag, the tag whose start state / reset() it shares, constructor arguments, action)
+MIX_CTOR = [("mix_re50_pe1e3_a0", "mix_re50_pe1e3_a0", dict(re=50.0, pe=1.0e3), 0),
+            ("mix_re50_pe1e3_a3", "mix_re50_pe1e3_a0", dict(re=50.0, pe=1.0e3), 3),
+            ("mix_re200_pe1e5_a1", "mix_re200_pe1e5_a1", dict(re=200.0, pe=1.0e5, side=0.3, C0=2.0), 1),
+            ("mix_re200_pe1e5_a2", "mix_re200_pe1e5_a1", dict(re=200.0, pe=1.0e5, side=0.3, C0=2.0), 2),
+            ("mix_re400_pe2e3_a0", "mix_re400_pe2e3_a0", dict(re=400.0, pe=2.0e3, side=0.62, C0=0.5), 0)]
+RAY_CTOR = [("ray_sgts5_ra5e4", dict(n_sgts=5, ra=5.0e4)), ("ray_sgts12_ra8e3_50x75", dict(n_sgts=12, ra=8.0e3, H=1.5)),
+            ("ray_sgts3_ra2e5", dict(n_sgts=3, ra=2.0e5))]
+
+
+@pytest.mark.parametrize("tag,t0,kw,act", MIX_CTOR, ids=[c[0] for c in MIX_CTOR])
+def test_mixing_constructor_arguments(tag, t0, kw, act):
+    """mixing(re, pe, side, C0) (mixing.py:21-34): u_max = re nu / L moves the lid speed (the transport's CFL number), pe its
+    diffusion number, side / C0 the patch of reset_fields (mixing.py:82-111) and the reward's reference level.  reset() and four
+    timesteps from a seeded state, with the reference's stage snapshots of the first one, bit for bit."""
+    g = golden("ctor_args")
+    e = O.mixing(**kw)
+    o0, _ = e.reset()
+    assert np.array_equal(o0, g[t0 + "_reset_obs"]) and np.array_equal(e.S, g[t0 + "_reset_C"])
+    assert e.get_rwd() == pytest.approx(float(g[t0 + "_reset_rwd"]), rel=RED)
+    fp = g[t0 + "_fparams"]
+    assert (e.cfg.re, e.cfg.pe, e.cfg.u_max) == (fp[5], fp[6], fp[7])
+    for i, f in enumerate("uvp"):
+        e.st[i] = g["%s_%s0" % (t0, f)]
+    e.cfg.ndt_act = 4
+    o, r, d, t, _ = e.step(np.int64(act))
+    assert np.array_equal(e.itp, g[tag + "_itp"])
+    assert np.array_equal(o, g[tag + "_obs"]) and r == pytest.approx(float(g[tag + "_rwd"]), rel=RED)
+    for f, F in (("u", "u"), ("v", "v"), ("p", "p"), ("S", "C")):
+        assert np.array_equal(getattr(e, f), g["%s_%s" % (tag, F)]), F
+    if tag == t0:
+        _stage_snapshots(e.cfg, g, tag, "C", 1)
+
+
+@pytest.mark.parametrize("tag,kw", RAY_CTOR, ids=[c[0] for c in RAY_CTOR])
+def test_rayleigh_constructor_arguments(tag, kw):
+    """rayleigh(n_sgts, ra) (rayleigh.py:20-27; nx_sgts = nx // n_sgts: with 12 or 3 segments on 50 cells the last bottom ghosts are
+    never written), one of them on the 50x75 grid of round 5's wrong kernel: five timesteps from a seeded state (stage snapshots of the first two), bit for bit."""
+    g = golden("ctor_args")
+    e = O.rayleigh(init=False, **kw)
+    e.reset_fields()
+    nx, ny, n_sgts, nx_sgts = (int(x) for x in g[tag + "_params"])
+    assert (e.nx, e.ny, e.cfg.n_sgts, e.cfg.nx_sgts) == (nx, ny, n_sgts, nx_sgts)
+    for i, f in enumerate("uvpT"):
+        e.st[i] = g["%s_%s0" % (tag, f)]
+    e.cfg.ndt_act = 5
+    a = g[tag + "_action"].tolist()
+    o, r, d, t, _ = e.step(a)
+    assert np.array_equal(np.array(a), g[tag + "_a_norm"])          # normalised in place (rayleigh.py:165-168)
+    assert np.array_equal(e.itp, g[tag + "_itp"])
+    assert np.array_equal(o, g[tag + "_obs"]) and r == pytest.approx(float(g[tag + "_rwd"]), rel=RED)
+    for f, F in (("u", "u"), ("v", "v"), ("p", "p"), ("S", "T")):
+        assert np.array_equal(getattr(e, f), g["%s_%s" % (tag, F)]), F
+    _stage_snapshots(e.cfg, g, tag, "T", 2)
+
+
+def _stage_snapshots(cfg, g, tag, sname, n):
+    """every kernel alone on the reference's own stage inputs of each timestep"""
+    import ctypes as C
+    L, dp = O.lib(), O.dp
+    for k in range(n):
+        u, v, p = (np.ascontiguousarray(g["%s_bc_%s" % (tag, x)][k]) for x in "uvp")
+        S = np.ascontiguousarray(g[tag + "_bc_T"][k]) if sname == "T" else np.zeros_like(u)
+        us, vs = np.zeros_like(u), np.zeros_like(u)
+        L.orc_ns2d_predictor(C.byref(cfg), dp(u), dp(v), dp(us), dp(vs), dp(p), dp(S))
+        assert np.array_equal(us, g[tag + "_pred_us"][k]) and np.array_equal(vs, g[tag + "_pred_vs"][k])
+        phi, phin, ovf = np.zeros(u.size), np.zeros(u.size), C.c_int(0)
+        itp = L.orc_ns2d_poisson(C.byref(cfg), dp(us), dp(vs), dp(phi), dp(phin), C.byref(ovf))
+        assert itp == g[tag + "_itp"][k] and not ovf.value
+        assert np.array_equal(phi.reshape(u.shape), g[tag + "_pois_phi"][k])
+        u2, v2 = u.copy(), v.copy()
+        L.orc_ns2d_corrector(C.byref(cfg), dp(u2), dp(v2), dp(us), dp(vs), dp(phi))
+        assert np.array_equal(u2, g[tag + "_corr_u"][k]) and np.array_equal(v2, g[tag + "_corr_v"][k])
+        T2 = np.ascontiguousarray(g[tag + "_tran_in"][k]).copy()
+        L.orc_ns2d_transport(C.byref(cfg), dp(u2), dp(v2), dp(T2))
+        assert np.array_equal(T2, g[tag + "_tran_out"][k])
+
+
 def test_poisson_manufactured_known_answer():
     """Jacobi on a zero right-hand side converges in one sweep with phi == 0; a divergent
     starred field gives a phi whose discrete Laplacian matches the rhs in the interior."""
