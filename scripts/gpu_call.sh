@@ -29,12 +29,14 @@ for what in "$@"; do
     smoke)   step smoke 300 python3 -c "import __graft_entry__ as g; g.smoke()" ;;
     f64t)    step f64tests 900 python3 -m pytest tests -m gpu -q -k "f64 or float64 or init_generation or identical"
              step kstat64 600 python3 scripts/kstat.py f64 6 ;;
+    k:*)     BEACON_ERRLOG=$OUT/errlog_k.jsonl step tests_k 900 python3 -m pytest tests -m gpu -q -k "${what#k:}" ;;
     kstat)   step kstat 600 python3 scripts/kstat.py f32 8 ;;
     kstat64) step kstat64 600 python3 scripts/kstat.py f64 6 ;;
     mixstat) step mixstat 600 python3 scripts/mixstat.py f32 6 ;;
     # diagnostic builds (they REPLACE the box's library: keep them behind everything that measures the product)
     stamp)   BEACON_NO_BUILD=0 step stamp 1100 python3 scripts/stamp2.py ;;
     stamp64) BEACON_NO_BUILD=0 BCN_STAMP_DTYPE=f64 step stamp64 1100 python3 scripts/stamp2.py ;;
+    stampmix) BEACON_NO_BUILD=0 step stampmix 1100 python3 scripts/stamp_mixing.py ;;
     dist)    step tests_dist 600 python3 -m pytest tests -m gpu -q -k "rccl or gloo or masked" ;;
     bench)   step bench 600 python3 bench.py --steps 20 --warmup 5 ;;
     benchq)  step benchq 600 python3 bench.py --steps 20 --warmup 5 --no-cpu --no-secondary ;;

@@ -1029,7 +1029,7 @@ def test_speculative_first_evaluation_never_changes_a_result(dtype):
                                             (1.2, 2.4, "f32", 5e-5), (2.2, 1.3, "f32", 5e-5), (1.0, 1.4, "f64", F64_TOL),
                                             (1.0, 3.0, "f32", 5e-5), (1.0, 3.0, "f64", F64_TOL), (1.28, 4.0, "f32", 5e-5),
                                             (1.0, 2.9, "f32", 5e-5), (1.0, 2.98, "f64", F64_TOL), (6.0, 1.0, "f32", 5e-5),
-                                            (1.06, 3.0, "f32", 5e-5), (1.0, 1.5, "f64", F64_TOL), (1.14, 2.14, "f64", F64_TOL)])
+                                            (1.06, 3.0, "f32", 5e-5), (1.0, 1.5, "f64", F64_TOL), (1.15, 2.14, "f64", F64_TOL)])
 def test_jit_grids_rayleigh_vs_oracle(L, H, dtype, tol):
     """The reference takes any L, H (rayleigh.py:20-27).  Grids without a built-in register-resident kernel get one
     instantiated for them (beacon_amd/jit.py): 75x50 (strips of 10 columns, the last wave 5), 53x50, 110x64, and 50x70,
@@ -1879,7 +1879,8 @@ RAY_CTOR = [("ray_sgts5_ra5e4", dict(n_sgts=5, ra=5.0e4)), ("ray_sgts12_ra8e3_50
             ("ray_sgts3_ra2e5", dict(n_sgts=3, ra=2.0e5))]
 # float32, four / five timesteps from the seeded states of tests/golden/ctor_args.npz (measured maxima in the comment of each test)
 F32["mix_ctor"] = f32tol(1e-6, 1e-6, 4e-6, 2.5e-6, 2.5e-6, 3e-7)
-F32["ray_ctor"] = f32tol(3e-7, 3e-7, 2.5e-6, 2.5e-6, 2.5e-6, 3e-5)
+# m (mixing, 5 cases): 3.3e-7 1.8e-7 6.0e-7 8.2e-7 2.4e-7 4.3e-8; m (rayleigh 50x50, 2 cases): 8.7e-9 1.4e-8 3.3e-8 1.9e-7 8.4e-8 2.6e-6
+F32["ray_ctor"] = f32tol(8e-8, 1.4e-7, 3.3e-7, 1.9e-6, 8e-7, 2.6e-5)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -1929,7 +1930,8 @@ def test_rayleigh_constructor_arguments_vs_reference(tag, kw, dtype):
     env.set_ndt_act(5)
     assert env.set_variant(1) == 1
     env.reset()
-    t = F32["ray_ctor"] if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, 50 * F64_TOL)
+    # (50x75 runs the two-rows-per-lane kernel: the tolerances of that family's on-demand grids)
+    t = (F32["ray_ctor"] if env.ny <= 64 else F32["ray_jit", 2]) if dtype == "f32" else f32tol(F64_TOL, F64_TOL, 50 * F64_TOL, F64_TOL, F64_TOL, 50 * F64_TOL)
     st0 = np.stack([g["%s_%s0" % (tag, f)] for f in "uvpT"])
     env.set_state(np.tile(ref_to_dev(st0)[None], (B, 1, 1, 1)))
     a = np.tile(g[tag + "_action"][None], (B, 1))
