@@ -5,7 +5,8 @@ from beacon_amd import build
 extra = sys.argv[1:]
 for x in [x for x in extra if x.startswith("-ffp-contract=")]:      # per-file flags come last on the command line
     build.FILE_FLAGS = {k: [f for f in v if not f.startswith("-ffp-contract=")] + [x] for k, v in build.FILE_FLAGS.items()}
-build.FLAGS.extend(["-DBCN_STAMP"] + extra); build.build_lib(force=True)
+if os.environ.get("BCN_STAMP_NOBUILD") != "1":      # (scripts/variants.py puts a -DBCN_STAMP library in place itself)
+    build.FLAGS.extend(["-DBCN_STAMP"] + extra); build.build_lib(force=True)
 from beacon_amd import vec as V
 z = np.load("tests/golden/rayleigh_128x64_init.npz")
 B = 512
