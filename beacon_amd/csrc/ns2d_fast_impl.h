@@ -75,7 +75,10 @@ struct FastGeom {
   static constexpr int SX = NX + 2;
   // +16: lanes >= NY read (never write) past the array; a multiple of 64 elements, so that the transport wave fetches
   // u and v of a cell (the same index in two consecutive arrays) with ONE ds_read2st64_b32
-  static constexpr int SZ = (SX * SY + 16 + 63) / 64 * 64;
+  // GF == 2 with a narrow last strip: ONE body serves every strip (fast_body: DEADC), the last one R columns wide like the
+  // others with RL of them live; its dead columns read (never write) up to R - RL + 1 columns past the east ghost column
+  static constexpr int DEADPAD = (GF == 2 && RL != R) ? (R - RL + 2) * SY : 0;
+  static constexpr int SZ = (SX * SY + 16 + DEADPAD + 63) / 64 * 64;
   static constexpr int PD = GF ? BCN_PDG : BCN_PDF;   // transport prefetch depth (diagonals); deeper for global fields
   // LDS map (elements): [ exchange 2*NW*2*64 | errp 128 | sact 64 | red 32 | sched 16 | .. FRONT ) U V T [ BACK )
   // The transport wave reads cell (t-lane+1, lane+1) for every lane without range checks: columns
@@ -302,6 +305,15 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   const int tid = threadIdx.x, lane = tid & 63;
   int j = lane + 1;   // GF: laundered at the phase boundaries (hipcc would hoist and spill a timestep's 64-bit addresses)
   const bool active = lane < NY;
+  // ONE body for every strip (float64 with T in the global scratch; VERDICT r05 item 2: the seam between two instantiations of
+  // this body in one kernel is where round 4's wrong float64 kernel had its wrong word).  The last strip is R0 columns wide like
+  // the others; its first RL columns exist, the others are DEAD: their registers hold finite values that nothing stores, their
+  // u*, v*, rhs are zero, the live east edge (column RL - 1) sees its Neumann ghost as a mirror cell in column RL, and the
+  // residual leaves them out.  LIVE(k): column k of THIS wave exists (compile time for k < RL and for every other grid).
+  constexpr int RL = G::RL;
+  constexpr bool DEADC = GF == 2 && RW == R0 && RL != R0;
+  const bool lastw = DEADC && w == NW - 1;
+#define LIVE(k) (!DEADC || (k) < RL || !lastw)
   const int i0 = w * R0 + 1;
   const size_t off = (size_t)b * A.ncell;
   real* __restrict__ gu = A.u + off;
@@ -325,7 +337,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   if (tid < 128) errp[tid] = 0;
   real p[R];
 #pragma unroll
-  for (int k = 0; k < R; k++) p[k] = active ? gp[j * SX + i0 + k] : real(0);
+  for (int k = 0; k < R; k++) p[k] = (active && LIVE(k)) ? gp[j * SX + i0 + k] : real(0);
 
   // ---- action conditioning (rayleigh.py:162-171); later chunks reuse the conditioned vector ----
   if (!first_chunk) {
@@ -357,7 +369,9 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   const real wl = active ? real(1) + (j == 1 ? 1 : 0) + ((j == NY && KIND == 0) ? 1 : 0) : real(0);
   const real fW = (active && w == 0) ? real(1) : real(0);
   const real fE = (active && w == NW - 1) ? real(1) : real(0);
-  const real cW = wl + fW, cE = wl + fE;   // weights of the strip's first / last column (ghost columns included)
+  // (one body, last strip: its register column R - 1 is dead -- weight 0 --, and the east ghost column counts with column RL - 1: fEl)
+  const real cW = wl + fW, cE = lastw ? real(0) : wl + fE;   // weights of the strip's first / last column (ghost columns included)
+  const real fEl = lastw ? fE : real(0);
   // coefficient of the lane's own value from the y-ghosts (bottom: always Neumann; top: rayleigh)
   const real cBy = cy * (real)((lane == 0 ? 1 : 0) + ((lane == NY - 1 && KIND == 0) ? 1 : 0));
   const real actf = active ? real(1) : real(0);
@@ -422,7 +436,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       real conv = (uE * uE - uW * uW) * rdx + (uN2 * vN2 - uS2 * vS2) * rdy;
       real diff = ((uE_ - 2 * uc + uW_) * rdx2 + (uN_ - 2 * uc + uS_) * rdy2) * A.kmom;
       real pres = (pc - pW) * rdx;
-      us_out = (i >= 2 && active) ? uc + dt * (diff - conv - pres) : real(0);
+      us_out = (i >= 2 && (!DEADC || i <= NX) && active) ? uc + dt * (diff - conv - pres) : real(0);
     }
     {
       real vE = real(0.5) * (vE_ + vc), vW = real(0.5) * (vc + vW_);
@@ -589,7 +603,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       for (int k = 0; k < R; k++) Tr[k] = Tl[(i0 + k) * SY + j];
       if (active) {   // (wave-uniform branches)
         if (w == 0) Tl[0 * SY + j] = Tr[0];
-        if (w == NW - 1) Tl[(NX + 1) * SY + j] = Tr[R - 1];
+        if (w == NW - 1) Tl[(NX + 1) * SY + j] = Tr[(DEADC ? RL : R) - 1];
       }
       // top and bottom ghost rows: the wall rows' values (lanes NY - 1 and 0) are broadcast, lane k < R stores column k of the
       // strip -- one store instruction per ghost row, no lane-divergent block
@@ -604,7 +618,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
         const int ii = i0 + (lane < R ? lane : 0);
         const int sg = (ii - 1) / A.nx_sgts;
         const real sa = sact[sg < A.n_sgts ? sg : 0];
-        if (lane < R) {
+        if (lane < (lastw ? RL : R)) {
           Tl[ii * SY + NY + 1] = gt;
           if (sg < A.n_sgts) Tl[ii * SY + 0] = 2 * (A.Th + sa) - gb;
         }
@@ -624,7 +638,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
 #pragma unroll
     for (int k = 0; k < R; k++) {
       const real buoy = (KIND == 0) ? (TREG ? Tr[TREG ? k : 0] : Tl[(i0 + k) * SY + j]) : real(0);
-      vs[k] = (j >= 2 && active) ? Vl[(i0 + k) * SY + j] + dt * (vx[k] + buoy) : real(0);   // (the old v: re-read, not kept)
+      vs[k] = (j >= 2 && active && LIVE(k)) ? Vl[(i0 + k) * SY + j] + dt * (vx[k] + buoy) : real(0);   // (the old v: re-read, not kept)
     }
     BCN_PH(0)
 
@@ -637,7 +651,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       for (int k = 0; k < R; k++) {
         const real ue = (k < R - 1) ? us[k < R - 1 ? k + 1 : 0] : usE;
         const real vn = from_above(real(0), vs[k]);                        // v*[., ny+1] = 0 (lanes >= NY hold 0)
-        nb[k] = active ? -A.cb * ((ue - us[k]) * rdx + (vn - vs[k]) * rdy) : real(0);
+        nb[k] = (active && LIVE(k)) ? -A.cb * ((ue - us[k]) * rdx + (vn - vs[k]) * rdy) : real(0);
       }
     }
     // rhs of the neighbouring strips' edge columns: the double sweeps below recompute those columns (depth-2 halos)
@@ -767,6 +781,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real pl = cell(SRC[R - 1], hE, SRC[R - 2], nb[R - 1]);                           \
       DST[0] = p0;                                                                           \
       DST[R - 1] = pl;                                                                       \
+      /* one body, last strip: the Neumann ghost east of the live edge, as a cell of the register row */ \
+      if constexpr (DEADC) DST[DEADC ? RL : 0] = lastw ? DST[DEADC ? RL - 1 : 0] : DST[DEADC ? RL : 0]; \
       BCN_PUBLISH(DST)
 #define BCN_PUBLISH(DST)                                                                     \
       exl(xb, w, 0) = DST[0];                                                                \
@@ -819,14 +835,19 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       BCN_CELLS(SRC, DST)                                                                    \
       BCN_NCHK_INC                                                                           \
       real acc = 0;                                                                          \
-      _Pragma("unroll") for (int k = 1; k < R - 1; k++) { const real d = DST[k] - SRC[k]; acc += d * d; } \
-      const real pI = wl * acc;                                                              \
+      _Pragma("unroll") for (int k = 1; k < R - 1; k++) {                                    \
+        real d = DST[k] - SRC[k];                                                            \
+        if (DEADC && k >= RL) d = lastw ? real(0) : d;   /* dead columns of the last strip */ \
+        acc += d * d;                                                                        \
+      }                                                                                      \
+      real pI = wl * acc;                                                                    \
+      if constexpr (DEADC) { const real de = DST[DEADC ? RL - 1 : 0] - SRC[DEADC ? RL - 1 : 0]; pI += fEl * (de * de); } \
       const real d0 = p0 - SRC[0], dl = pl - SRC[R - 1];                                     \
       const real part = pI + cW * (d0 * d0) + cE * (dl * dl);                                \
       const real tot63 = wave_sum_lane63<real>(part);                                        \
       if (lane == 63) errp[xb * 64 + w] = tot63;                                             \
       if (plan == 1) {   /* the proven plan needs the unweighted interior norm too (lanes past the top row hold zeros) */ \
-        const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + dl * dl);                  \
+        const real totu63 = wave_sum_lane63<real>(acc + d0 * d0 + (lastw ? real(0) : dl * dl)); \
         if (lane == 63) errp[xb * 64 + 16 + w] = totu63;                                     \
       }                                                                                      \
       __syncthreads();                                                                       \
@@ -1108,8 +1129,8 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       const real ps = from_below(ph, ph);
       p[k] += ph;
       if (active) {
-        if (i >= 2) Ul[i * SY + j] = us[k] - dt * (ph - pw) * rdx;
-        if (j >= 2) Vl[i * SY + j] = vs[k] - dt * (ph - ps) * rdy;
+        if (i >= 2 && LIVE(k)) Ul[i * SY + j] = us[k] - dt * (ph - pw) * rdx;
+        if (j >= 2 && LIVE(k)) Vl[i * SY + j] = vs[k] - dt * (ph - ps) * rdy;
       }
     }
     __syncthreads();
@@ -1151,7 +1172,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
       __syncthreads();   // every read of the old T is done
       if (active) {
 #pragma unroll
-        for (int k = 0; k < R; k++) Tl[(i0 + k) * SY + j] = Ac[k];
+        for (int k = 0; k < R; k++) if (LIVE(k)) Tl[(i0 + k) * SY + j] = Ac[k];
       }
     }
     __syncthreads();
@@ -1171,6 +1192,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
     for (int k = 0; k < R; k++) {
       const int i = i0 + k, c = j * SX + i;
       // a p ghost receives the same increments as its interior neighbour (phi ghosts copy it)
+      if (!LIVE(k)) continue;
       const real dp = p[k] - gp[c];
       if (i == 1) gp[c - 1] += dp;
       if (i == NX) gp[c + 1] += dp;
@@ -1197,6 +1219,7 @@ __device__ __forceinline__ void fast_body(const NS2DArgs<real>& A, const int w, 
   } else if (tid == 0) {
     A.status[b] = status;
   }
+#undef LIVE
   if (tid == 0 && A.cyc) {   // this replica's units run one after the other (chunk hand-off): plain read-modify-write
     A.cyc[4 * (size_t)b] += cyc_j;
     A.cyc[4 * (size_t)b + 1] += __builtin_amdgcn_s_memtime() - cyc_u0;
@@ -1211,7 +1234,8 @@ __device__ __forceinline__ void fast_unit(const NS2DArgs<real>& A, const int b, 
                                           const bool first_chunk, const bool last_chunk, char* smem) {
   using G = FastGeom<NX, NY, R, GF>;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (G::RL != R && w == G::NW - 1) fast_body<real, NX, NY, R, G::RL, KIND, EQ, GF>(A, w, b, it_begin, it_end, first_chunk, last_chunk, smem);
+  // (GF == 2 -- float64, T in the global scratch --: ONE body, the narrow last strip's surplus columns dead: fast_body, DEADC)
+  if (GF != 2 && G::RL != R && w == G::NW - 1) fast_body<real, NX, NY, R, G::RL, KIND, EQ, GF>(A, w, b, it_begin, it_end, first_chunk, last_chunk, smem);
   else fast_body<real, NX, NY, R, R, KIND, EQ, GF>(A, w, b, it_begin, it_end, first_chunk, last_chunk, smem);
 }
 

@@ -42,8 +42,11 @@ def _up16(x):
     return (x + 15) // 16 * 16
 
 
-def _lds_rows1(nx, ny, nw, esz, gf):
-    sy, sz = ny + 2, ((nx + 2) * (ny + 2) + 16 + 63) // 64 * 64
+def _lds_rows1(nx, ny, nw, esz, gf, r=0):
+    sy = ny + 2
+    rl = nx - (nw - 1) * r if r else 0
+    deadpad = (r - rl + 2) * sy if (gf == 2 and r and rl != r) else 0      # FastGeom::DEADPAD: the one-body form's dead columns
+    sz = ((nx + 2) * (ny + 2) + 16 + deadpad + 63) // 64 * 64
     misc = 2 * nw * (2 if gf == 2 else 4) * 64 + 224 + 16
     front = _up16(max(misc, 63 * sy + 1))
     back = (ny + 3 * 8 + 2) * sy
@@ -95,17 +98,16 @@ def choose(nx, ny, f64, kind):
             rl = nx - (nw - 1) * r
             if r > rmax or rl < 3 or rl > r or (nw - 1) * r >= nx:
                 continue
-            # float64: strips of equal width only (one instantiation of the body), and at most 16 columns per lane.  The
-            # two-body float64 kernel of 110x64 (strips of 14 and 12 columns, u, v in LDS, T in the global scratch, strip 0
-            # handed to the helper waves) computed ONE wrong word per timestep under a neutral source change -- lane 0 of the
-            # column where the two bodies meet, in every replica, at every batch size, whatever the data; 6 of 21 unrelated
-            # code-generation flags make the same source exact (code generation at the register limit,
-            # not a race).  Such grids take the hybrid kernel of ns2d_fast4_impl.h (below); every plugin, of whatever family,
+            # float64: at most 16 columns per lane.  Strips of unequal width: round 4's two-body float64 kernel of 110x64 (strips of
+            # 14 and 12 columns, two instantiations of the body in one kernel) computed ONE wrong word per timestep under a neutral
+            # source change -- lane 0 of the column where the two bodies meet.  Since round 6 the float64 kernel with
+            # T in the global scratch (gf = 2) has ONE body: the last strip is as wide as the others, its surplus columns dead
+            # (ns2d_fast_impl.h: DEADC); the all-global variant (gf = 1) keeps equal strips only.  Every plugin, of whatever family,
             # is compared with the generic kernel before its first use (verify()).
-            if f64 and (rl != r or r > 16):
+            if f64 and r > 16:
                 continue
-            for gf in ((0,) if not f64 else (2, 1)):
-                if _lds_rows1(nx, ny, nw, esz, gf) <= LDS_BYTES:
+            for gf in ((0,) if not f64 else ((2, 1) if rl == r else (2,))):
+                if _lds_rows1(nx, ny, nw, esz, gf, r) <= LDS_BYTES:
                     return {"rows": 1, "R": r, "gf": gf, "nw": nw}
     elif 64 < ny <= 128:
         # float64: the fields live in a global scratch, the Poisson rhs in LDS (gf = 1); rayleigh and mixing alike

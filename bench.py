@@ -800,6 +800,25 @@ def main():
                          "source": "profiles/" + vi["source"]})
             sys.stderr.write("bench.py: VALU / HBM counters rescaled from profiles/%s (%.4g sweeps per dispatch there, %.4g per "
                              "launch in this run)\n" % (vi["source"], vi["sweeps_per_dispatch"], sweeps_per_launch))
+        # Cross-check of that figure: instructions from a MODEL instead of a rescaled total -- static x sweeps +
+        # per_timestep x timesteps, where `static` is the compiler's own VALU count of the plain double sweep (scripts/valu_model.py
+        # -> profiles/r06_valu_model.json: 178 per wave and pair = 712 per replica-sweep; the PMC fit between the default and the
+        # zero-action profile gives 711.3) and `per_timestep` is what the zero-action profile (one sweep per solve) leaves
+        # (profiles/r06_valu_fit.json).  This run's own sweep counts go in; the two figures must agree to a few per cent.
+        try:
+            fit = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_fit.json")))
+            if fit.get("kernel", "").startswith(kname + "<") and args.dtype == "f32" and grid_tag in fit["kernel"]:
+                ts_per_launch = float(B * env.ndt_act)
+                im = fit["valu_per_replica_sweep_static"] * sweeps_per_launch + fit["valu_per_replica_timestep_outside_plain_sweeps"] * ts_per_launch
+                roof["instructions_model"] = {
+                    "instructions": im, "achieved": im / launch_s, "frac": im / launch_s / VALU_ISSUE_PEAK,
+                    "valu_per_replica_sweep_static": fit["valu_per_replica_sweep_static"],
+                    "valu_per_replica_sweep_fitted": fit["valu_per_replica_sweep_fitted"],
+                    "valu_per_replica_timestep": fit["valu_per_replica_timestep_outside_plain_sweeps"],
+                    "model_over_profile_scaled": (im / launch_s) / roof["achieved"] if roof.get("achieved") else None,
+                    "source": "profiles/r06_valu_model.json (hipcc -S of the kernel), profiles/r06_valu_fit.json (two PMC profiles)"}
+        except (OSError, ValueError, KeyError) as e:
+            roof["instructions_model"] = {"error": "%s: %s" % (type(e).__name__, e)}
         roof["hbm_effective"] = hbm_eff
         tr = committed_profile(kname, "hbm_bytes_per_dispatch", args.dtype, grid_tag)
         if tr:
