@@ -54,6 +54,16 @@ class _Single(object):
     def stp(self):
         return int(self.vec.get_stp()[0])
 
+    def _obs_view(self, t):
+        """rayleigh.py:243-262 / mixing.py:237-258: get_obs() fills the env's own history array `self.obs`
+        [n_obs_steps, 3, nx_obs_pts, ny_obs_pts] in place and returns np.reshape(self.obs, [-1]) -- a VIEW: an observation a
+        caller kept from the previous step shows the new values after the next one.  Same here: one array per env, refilled."""
+        new = self._np(t)[0]
+        if getattr(self, "obs", None) is None:
+            self.obs = np.zeros((self.n_obs_steps, 3, self.nx_obs_pts, self.ny_obs_pts))
+        self.obs[...] = new.reshape(self.obs.shape)
+        return np.reshape(self.obs, [-1])
+
 
 def _fields_2d(state):
     """device layout [4, ny+2, nx+2] -> the reference's four [nx+2, ny+2] arrays"""
@@ -85,7 +95,7 @@ class rayleigh(_Single):
         self.a = [0.0] * self.n_sgts
         self.stp_plot = 0
         self.nu = np.empty((0, 2))                # (stp, Nusselt) per step since reset (rayleigh.py:124)
-        return self._np(obs)[0], None
+        return self._obs_view(obs), None
 
     def step(self, a=None):
         if a is None:
@@ -101,7 +111,7 @@ class rayleigh(_Single):
         done, trunc = self._episode()
         rwd = float(self.vec.rwd[0].item())
         self.nu = np.append(self.nu, np.array([[self.stp - 1, -rwd]]), axis=0)   # get_rwd records (stp, nu) (:273)
-        return self._np(self.vec.obs)[0], rwd, done, trunc, None
+        return self._obs_view(self.vec.obs), rwd, done, trunc, None
 
     def _field(self, k):
         return _fields_2d(self.vec.get_state())[k]
@@ -143,7 +153,8 @@ class mixing(_Single):
         self.vec = vec.VecMixing(1, device, dtype, L, H, re, pe, side, C0)
         v = self.vec
         for k in ("L", "H", "nx", "ny", "re", "pe", "C0", "side", "u_max", "dt", "dt_act", "ndt_act", "n_act",
-                  "dx", "dy", "n_obs_tot", "nx_obs", "ny_obs", "action_space", "observation_space"):
+                  "dx", "dy", "n_obs_tot", "nx_obs", "ny_obs", "nx_obs_pts", "ny_obs_pts", "n_obs_steps", "action_space",
+                  "observation_space"):
             setattr(self, k, getattr(v, k))
         self.a = 1
 
@@ -151,7 +162,7 @@ class mixing(_Single):
         obs, _ = self.vec.reset()
         self.a = 1
         self.stp_plot = 0
-        return self._np(obs)[0], None
+        return self._obs_view(obs), None
 
     def step(self, a=None):
         if a is None:
@@ -161,7 +172,7 @@ class mixing(_Single):
             self.vec.step(np.asarray([int(a)]))
         self.vec.check_status()
         done, trunc = self._episode()
-        return self._np(self.vec.obs)[0], float(self.vec.rwd[0].item()), done, trunc, None
+        return self._obs_view(self.vec.obs), float(self.vec.rwd[0].item()), done, trunc, None
 
     def _field(self, k):
         return _fields_2d(self.vec.get_state())[k]

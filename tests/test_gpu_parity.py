@@ -2913,6 +2913,57 @@ def test_slow_mode_landing_guard_never_changes_a_result():
 
 
 # ---- the two bindings of the C ABI -------------------------------------------------------------
+def test_2d_env_observations_are_views_of_the_envs_history_array():
+    """rayleigh.py:243-262 / mixing.py:237-258: get_obs() refills the env's own `self.obs` [4, 3, nx_obs_pts, ny_obs_pts] and returns
+    np.reshape(self.obs, [-1]) -- a view, so an observation kept from reset() shows the next step's values (SURVEY 8b "Ownership").
+    The drop-in mirrors do the same."""
+    for env, a in ((E.rayleigh(dtype="f32"), [0.1] * 10), (E.mixing(dtype="f32"), np.int64(2))):
+        env.vec.set_ndt_act(3)
+        o0, _ = env.reset()
+        assert o0.dtype == np.float64 and o0.shape == (env.n_obs_tot,) and np.shares_memory(o0, env.obs)
+        kept = o0.copy()
+        o1 = env.step(a)[0]
+        assert np.shares_memory(o1, env.obs) and np.shares_memory(o0, o1)
+        assert np.array_equal(o0, o1) and not np.array_equal(o0, kept)      # the kept handle moved with the env
+        n = 3 * env.nx_obs_pts * env.ny_obs_pts
+        assert np.array_equal(o1[2 * n:3 * n], kept[3 * n:])                 # history shifted by one slot (newest last)
+        env.close()
+
+
+def test_torch_ops_refuse_short_or_foreign_tensors():
+    """every tensor a torch.ops.beacon.* call receives is checked against the handle -- element count (obs, rwd, done,
+    trunc, status, sweeps [B][ndt_act], actions, noise), dtype and device -- BEFORE the library sees a pointer: a short buffer is an
+    error, not an out-of-bounds write on the device.  Meta kernels are registered (the ops return nothing)."""
+    from beacon_amd import torch_ext
+    ops = torch_ext.load()
+    assert ops is not None
+    env = V.VecBurgers(4, DEV, "f32", nx=512)
+    env.reset()
+    h = env.h.value
+    good = dict(obs=env.obs, rwd=env.rwd, done=env.done, trunc=env.trunc, status=env.status)
+    a = torch.zeros(4, device=DEV)
+
+    def call(**kw):
+        t = dict(good, **kw)
+        ops.burgers_step(h, kw.get("actions", a), kw.get("noise", None), t["obs"], t["rwd"], t["done"], t["trunc"], t["status"])
+    call()
+    for bad in (dict(done=torch.zeros(3, dtype=torch.uint8, device=DEV)), dict(status=torch.zeros(2, dtype=torch.int32, device=DEV)),
+                dict(actions=torch.zeros(3, device=DEV)), dict(noise=torch.zeros(5, device=DEV)), dict(rwd=torch.zeros(4, device=DEV, dtype=torch.float64)),
+                dict(trunc=torch.zeros(4, dtype=torch.uint8)), dict(obs=torch.zeros(env.obs.numel() - 1, device=DEV))):
+        with pytest.raises(RuntimeError):
+            call(**bad)
+    env.close()
+    env = V.VecMixing(2, DEV, "f32")
+    env.set_ndt_act(3)
+    env.use_torch_ops(True)
+    env.reset()
+    with pytest.raises(RuntimeError):      # sweeps is [B][ndt_act]
+        ops.mixing_step(env.h.value, None, env.obs, env.rwd, env.done, env.trunc, env.status, torch.zeros((2, 2), dtype=torch.int32, device=DEV))
+    env.close()
+    m = torch.empty(4, device="meta")
+    ops.burgers_reset(0, m)                # a Meta kernel exists: nothing to compute, nothing dereferenced
+
+
 def test_torch_ops_and_ctypes_bindings_step_every_env_bit_identically():
     """reset() / step() through torch.ops.beacon.* (csrc/torch/beacon_torch.cpp: one dispatcher call, stream read in C++) and
     through ctypes call the same bcn_* entry points: three steps, a masked reset and another step of every env family give
