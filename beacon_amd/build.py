@@ -26,7 +26,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=h
 
 # per-file flags.  ns2d_fast: the SLP vectoriser packs the Jacobi arithmetic into v_pk_* ops at the
 # price of many register shuffles -- measured slower than the scalar stream on gfx950.
-FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on"], "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on"],
+# ns2d_fast2 (256 VGPRs + ~100 spilled): without the scheduler's "unclustered high register pressure" re-scheduling stage the phases
+# outside the Jacobi loop lose fewer cycles to spills than the loop gains -- measured twice, A/B/A/B on one box (round 6,
+# scripts/variants.py): mixing 100x100 B=512 float32 29.83 -> 29.56 ms, float64 89.7 -> 88.2; the same flag on ns2d_fast: no gain.
+# (nine other scheduler switches -- max-ilp / max-memory-clause / iterative-minreg strategies, AMDGPU trackers, no post-RA scheduler, no
+# memop clustering, metric bias 0 / 100 -- gained nothing on any of the three kernels: profiles/r06_sched_flags_ab.log)
+FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on"],
+              "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
               # float64 1D kernels: the reference's operation order without FMA contraction -> bit-identical fields
               "env1d_f64.hip": ["-ffp-contract=off"]}
 
