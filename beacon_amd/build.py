@@ -28,13 +28,24 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=h
 # price of many register shuffles -- measured slower than the scalar stream on gfx950.
 # ns2d_fast2 (256 VGPRs + ~100 spilled): without the scheduler's "unclustered high register pressure" re-scheduling stage the phases
 # outside the Jacobi loop lose fewer cycles to spills than the loop gains -- measured twice, A/B/A/B on one box (round 6,
-# scripts/variants.py): mixing 100x100 B=512 float32 29.83 -> 29.56 ms, float64 89.7 -> 88.2; the same flag on ns2d_fast: no gain.
+# scripts/variants.py): mixing 100x100 B=512 float32 29.83 -> 29.56 ms, float64 89.7 -> 88.2; the same flag on ns2d_fast: no gain.  Without the SDWA
+# peephole on top: 29.92 -> 29.66 (1 301 -> 1 270 cycles per sweep).
 # (nine other scheduler switches -- max-ilp / max-memory-clause / iterative-minreg strategies, AMDGPU trackers, no post-RA scheduler, no
 # memop clustering, metric bias 0 / 100 -- gained nothing on any of the three kernels: profiles/r06_sched_flags_ab.log)
-FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on"],
-              "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"],
+# ns2d_fast.hip (the float32 instantiations; the float64 ones are ns2d_fast_f64.hip, the same source): -O2 -- measured A/B/A/B on one
+# box (round 6): the headline kernel 781 -> 772 cycles per sweep, 18.37 -> 18.18 ms over kstat's 8 steps; the float64 kernel loses
+# 0.7 % with it and keeps -O3 (profiles/r06_sched_flags_ab.log)
+FILE_FLAGS = {"ns2d_fast.hip": ["-fno-slp-vectorize", "-ffp-contract=on", "-O2"],
+              "ns2d_fast_f64.hip": ["-fno-slp-vectorize", "-ffp-contract=on"],
+              "ns2d_fast2.hip": ["-fno-slp-vectorize", "-ffp-contract=on", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule",
+                                 "-mllvm", "-amdgpu-sdwa-peephole=0"],
               # float64 1D kernels: the reference's operation order without FMA contraction -> bit-identical fields
               "env1d_f64.hip": ["-ffp-contract=off"]}
+
+
+# the on-demand kernels (beacon_amd/jit.py: csrc/jit/ns2d_jit.hip, any family, any precision): the flags their verification and
+# timings were made with
+JIT_FLAGS = ["-fno-slp-vectorize", "-ffp-contract=on"]
 
 
 def hipcc():

@@ -55,9 +55,14 @@ size_t ns2d_fast_scratch_elems(const NS2DArgs<real>& a) {
   if (fast_config<real>(a) == 3) return FastGeom<128, 64, BCN_R128D, BCN_GFD>::scratch_elems();
   return 0;
 }
+// One translation unit per precision (ns2d_fast_f64.hip includes this file with BCN_FAST_TU_F64): the two are built with different
+// optimisation levels -- the float32 kernels gain 1 % from -O2, the float64 ones lose 0.7 % (beacon_amd/build.py, round 6)
+#ifndef BCN_FAST_TU_F64
 template size_t ns2d_fast_scratch_elems<float>(const NS2DArgs<float>&);
-template size_t ns2d_fast_scratch_elems<double>(const NS2DArgs<double>&);
 template bool ns2d_fast_supported<float>(const NS2DArgs<float>&);
-template bool ns2d_fast_supported<double>(const NS2DArgs<double>&);
 template int ns2d_launch_fast<float>(const NS2DArgs<float>&, int, hipStream_t);
+#else
+template size_t ns2d_fast_scratch_elems<double>(const NS2DArgs<double>&);
+template bool ns2d_fast_supported<double>(const NS2DArgs<double>&);
 template int ns2d_launch_fast<double>(const NS2DArgs<double>&, int, hipStream_t);
+#endif

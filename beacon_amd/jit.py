@@ -281,7 +281,7 @@ def selftest(device="cuda:0", verbose=False):
 
 def _signature(defs):
     h = hashlib.sha256()
-    h.update(repr((_build.ARCH, _build.FLAGS, _build.FILE_FLAGS.get("ns2d_fast.hip"), sorted(defs.items()))).encode())
+    h.update(repr((_build.ARCH, _build.FLAGS, _build.JIT_FLAGS, sorted(defs.items()))).encode())
     for f in sorted([JIT_SRC] + [os.path.join(_build.CSRC, n) for n in os.listdir(_build.CSRC) if n.endswith(".h")] +
                     [os.path.join(_build.INC, n) for n in os.listdir(_build.INC) if n.endswith(".h")]):
         h.update(os.path.basename(f).encode())
@@ -318,7 +318,7 @@ def build_plugin(nx, ny, f64, kind, verbose=False, extra_defs=None):
             try:
                 if os.path.exists(path):
                     return path
-                cmd = ([cc] + _build.FLAGS + _build.FILE_FLAGS.get("ns2d_fast.hip", []) +
+                cmd = ([cc] + _build.FLAGS + _build.JIT_FLAGS +
                        ["-D%s=%s" % kv for kv in sorted(defs.items())] + ["-I", _build.INC, "-shared", JIT_SRC, "-o", tmp])
                 if verbose:
                     print(" ".join(cmd), flush=True)

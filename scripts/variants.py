@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from beacon_amd import build as B
 VDIR = os.path.join(B.PKG, "_variants")
 CACHE = "/tmp/bcn_variant_objs"
-HOT = ("ns2d_fast.hip", "ns2d_fast2.hip")
+HOT = ("ns2d_fast.hip", "ns2d_fast_f64.hip", "ns2d_fast2.hip")
 
 
 def compile_one(src, extra, out):
