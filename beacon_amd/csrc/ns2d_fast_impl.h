@@ -123,6 +123,13 @@ struct FastGeom {
 // cycles whatever its kind: 14 -> 10 instructions per steady step; the ragged first and last thirds of the sweep carry three
 // mask instructions more.
 typedef float v2f __attribute__((ext_vector_type(2)));
+// The wait state in front of the chain's DPP step.  A VALU write of a VGPR needs two wait states before a DPP read of it; the DPP
+// source is the previous step's result, and between its last writer (the previous v_fmac_f32_dpp, or the v_cndmask of the masked
+// phases) and this DPP read there is always the plain v_fmac that forms A + aW * west, which reads it too: ONE more wait state
+// suffices.  s_nop 1 -> s_nop 0: 24.27 k -> 23.68 k cycles per timestep outside the solve (3 cycles x 191 steps of a lone wave; round 6).
+#ifndef BCN_CHAIN_NOP
+#define BCN_CHAIN_NOP "s_nop 0\n\t"
+#endif
 template <int NX, int NY, int R>
 __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const float* Ul, float* dummy, float c0x, float c1x,
                                                               float c0y, float c1y) {
@@ -172,7 +179,7 @@ __device__ __attribute__((noinline)) void transport_chain_f32(float* Tl, const f
       const int t = t0 + (OFF) + q;                                                           \
       const float aw = awp[q / 2][q & 1], as = asp[q / 2][q & 1];                             \
       float t1 = RA[q] + aw * tp;                                                             \
-      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
+      asm volatile(BCN_CHAIN_NOP "v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" \
                    : "+v"(t1) : "v"(tp), "v"(as));                                            \
       okq[q] = (MASK == 0) || (MASK == 4 ? (lane <= t) : (active && (MASK != 2 ? (lane <= t) : true) && \
                                (MASK != 1 ? (lane > t - NX && t < NSTEP) : true)));           \
