@@ -376,7 +376,9 @@ TEST_GRIDS = [(75, 50, False, 0), (75, 50, True, 0), (53, 50, False, 0), (110, 6
               (100, 200, False, 1), (50, 145, False, 0), (50, 149, True, 0), (100, 130, False, 1),
               (300, 50, False, 0), (200, 100, False, 1), (53, 150, False, 0), (106, 200, False, 1),
               # float64, two rows per lane, ODD ny, strips of unequal width (9 / 5, 10 / 7): the class of the wrong kernel of round 5
-              (50, 75, True, 0), (57, 107, True, 0), (100, 105, True, 1), (50, 75, False, 0)]
+              (50, 75, True, 0), (57, 107, True, 0), (100, 105, True, 1), (50, 75, False, 0),
+              # float64, one row per lane, ONE body with dead columns in the last strip (round 6): 7 x 7 + 3 live, 7 x 16 + 13 live
+              (52, 50, True, 0), (125, 55, True, 0)]
 
 
 def fuzz_grids(seed=5):

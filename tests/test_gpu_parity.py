@@ -2726,6 +2726,24 @@ def test_jit_fuzzed_grids_agree_with_the_generic_kernel(idx):
     assert ok, rep
 
 
+@pytest.mark.parametrize("L,H,live,R", [(2.2, 1.28, 12, 14), (1.5, 1.0, 5, 10), (1.04, 1.0, 3, 7), (2.5, 1.1, 13, 16)])
+def test_float64_one_body_kernels_with_dead_columns(L, H, live, R):
+    """float64 one-row-per-lane kernels whose strips are not all equally wide run ONE body since round 6: the last strip is R columns
+    wide like the others, `live` of them exist, the others are dead (ns2d_fast_impl.h: DEADC) -- round 4's two-body kernel
+    of 110x64 computed one wrong word per timestep.  12 timesteps with other constructor arguments (n_sgts = 7, ra = 3e4), plain
+    launch and ticket scheduler, against the generic kernel: 1e-9 with sweep counts within 1 (measured: 7e-16, equal)."""
+    from beacon_amd import jit
+    nx, ny = int(50 * L), int(50 * H)
+    m = jit.choose(nx, ny, True, 0)
+    assert m["rows"] == 1 and m["gf"] == 2 and m["R"] == R and nx - (m["nw"] - 1) * R == live
+    mk = lambda B: V.VecRayleigh(B, DEV, "f64", None, L=L, H=H, n_sgts=7, ra=3.0e4)
+    env = mk(2)
+    assert env._plugin is not None and env._plugin.verified is True and env.kernel_name in ("ns2d_fast_step", "ns2d_generic_step")
+    env.close()
+    ok, rep = jit.compare_with_generic(mk, 0, True, ndt=12, batch=4)
+    assert ok, rep
+
+
 def test_jit_no_plugin_of_the_test_grids_was_refused():
     """Every grid of jit.TEST_GRIDS and of the fuzz list: its plugin is built, attaches, and carries a PASSED self-check on
     this box (a refused one is already an error through JitWarning; this is the inventory -- no `.bad` marker anywhere in
